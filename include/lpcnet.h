@@ -1,0 +1,75 @@
+/* lpcnet.h -- public C API of the MI355X-native LPCNet synthesis engine.
+ *
+ * Drop-in for the synthesis + decoder subset of xiph/LPCNet's include/lpcnet.h (tag 2024_10_08):
+ * same names, signatures, argument meaning and return conventions, so a program written against
+ * the reference header (e.g. src/lpcnet_demo.c -synthesis / -decode) links against
+ * liblpcnet_hip.so unchanged.  Each declaration cites the reference declaration it replaces.
+ * The encoder / feature-extraction / PLC entry points of the reference header are outside this
+ * engine's scope and are not exported.
+ *
+ * Differences a caller can observe:
+ *   - The trained model is never compiled in: lpcnet_load_model() must be called on every state
+ *     before lpcnet_synthesize() (the reference behaves like this when built with
+ *     -DUSE_WEIGHTS_FILE, src/lpcnet.c:192-196, src/lpcnet_demo.c:205-207).
+ *   - Arithmetic follows the reference's generic-C float path bit for bit (not its AVX2/NEON
+ *     approximations); only float ("DISABLE_DOT_PROD") blobs are accepted in this round.
+ *   - All compute runs on a HIP device; there is no CPU fallback.  If no device is usable,
+ *     lpcnet_load_model() returns -1 and lpcnet_hip_last_error() says why.
+ */
+#ifndef LPCNET_H_
+#define LPCNET_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef LPCNET_EXPORT
+# if defined(__GNUC__)
+#  define LPCNET_EXPORT __attribute__ ((visibility ("default")))
+# else
+#  define LPCNET_EXPORT
+# endif
+#endif
+
+#define NB_FEATURES 20                      /* reference include/lpcnet.h:45 */
+#define NB_TOTAL_FEATURES 36                /* :46 */
+#define LPCNET_COMPRESSED_SIZE 8            /* :49 bytes per packet */
+#define LPCNET_PACKET_SAMPLES (4*160)       /* :51 */
+#define LPCNET_FRAME_SIZE (160)             /* :53 */
+
+typedef struct LPCNetState LPCNetState;         /* :55 */
+typedef struct LPCNetDecState LPCNetDecState;   /* :57 */
+
+/* ---- decoder (reference include/lpcnet.h:67-96) ------------------------------------------ */
+LPCNET_EXPORT int lpcnet_decoder_get_size(void);                                   /* :67 */
+LPCNET_EXPORT int lpcnet_decoder_init(LPCNetDecState *st);                         /* :76, returns 0 */
+LPCNET_EXPORT LPCNetDecState *lpcnet_decoder_create(void);                         /* :83 */
+LPCNET_EXPORT void lpcnet_decoder_destroy(LPCNetDecState *st);                     /* :88 */
+/* 8 bytes in -> 640 samples out; returns 0 (:96, src/lpcnet.c:310-319) */
+LPCNET_EXPORT int lpcnet_decode(LPCNetDecState *st, const unsigned char *buf, short *pcm);
+
+/* ---- synthesis (reference include/lpcnet.h:78, :160-188, :214) ---------------------------- */
+LPCNET_EXPORT void lpcnet_reset(LPCNetState *lpcnet);                              /* :78 */
+LPCNET_EXPORT int lpcnet_get_size(void);                                           /* :160 */
+LPCNET_EXPORT int lpcnet_init(LPCNetState *st);                                    /* :169, returns 0 */
+LPCNET_EXPORT LPCNetState *lpcnet_create(void);                                    /* :174 */
+LPCNET_EXPORT void lpcnet_destroy(LPCNetState *st);                                /* :179 */
+/* one frame-network step on features[0..19] followed by N (<=160) output samples (:188) */
+LPCNET_EXPORT void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N);
+/* bind a "DNNw" weight blob; 0 on success, -1 on a malformed blob or missing device (:214).
+ * Unlike the reference the blob is copied to the device and need not outlive the state. */
+LPCNET_EXPORT int lpcnet_load_model(LPCNetState *st, const unsigned char *data, int len);
+
+/* ---- additions (not in the reference) ------------------------------------------------------ */
+/* message of the last failure on the calling thread ("" if none) */
+LPCNET_EXPORT const char *lpcnet_hip_last_error(void);
+/* install the VQ codebooks used by lpcnet_decode (the reference compiles them in from
+ * ceps_codebooks.c, a generated file that is not part of its tree): cb1..3 [1024][17], diff4 [4096][18] */
+LPCNET_EXPORT void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4);
+/* release every device resource held for the single-stream API (optional, e.g. before exit) */
+LPCNET_EXPORT void lpcnet_hip_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+/* lpcnet_batch.h -- batched multi-stream extension of the LPCNet C API (additive).
+ *
+ * The reference library is one-state-one-stream and single threaded (src/lpcnet.c has no
+ * threading); the MI355X engine gets its throughput from thousands of independent streams, so
+ * this header adds a batch object that owns the per-stream state on the device.  A batch is
+ * semantically n independent LPCNetState objects driven in lock step:
+ *   lpcnet_batch_synthesize(b, F, stride, P, T)  ==  for every stream s, for t < T:
+ *       lpcnet_synthesize(state[s], &F[(s*T + t)*stride], &P[(s*T + t)*160], 160)
+ * Streams never interact, so several batches (one per GPU, one process per GPU) shard a workload
+ * with no communication.
+ */
+#ifndef LPCNET_BATCH_H_
+#define LPCNET_BATCH_H_
+
+#include "lpcnet.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct LPCNetBatch LPCNetBatch;
+
+/* n_streams independent synthesis states on HIP device `device`; NULL on failure. */
+LPCNET_EXPORT LPCNetBatch *lpcnet_batch_create(int n_streams, int device);
+LPCNET_EXPORT void lpcnet_batch_destroy(LPCNetBatch *b);
+LPCNET_EXPORT int lpcnet_batch_streams(const LPCNetBatch *b);
+/* like lpcnet_load_model(): 0 or -1.  The blob is copied; it may be freed afterwards. */
+LPCNET_EXPORT int lpcnet_batch_load_model(LPCNetBatch *b, const unsigned char *data, int len);
+/* lpcnet_reset() on streams [first, first+count) */
+LPCNET_EXPORT int lpcnet_batch_reset(LPCNetBatch *b, int first, int count);
+
+/* Host-pointer synthesis: features [n_streams][n_frames][feat_stride] (only [0..19] of a frame are
+ * read, feat_stride >= 20; 36 = `lpcnet_demo -synthesis` file layout), pcm [n_streams][n_frames*160].
+ * Copies in, runs, copies out, synchronises.  Returns 0 or a negative error code. */
+LPCNET_EXPORT int lpcnet_batch_synthesize(LPCNetBatch *b, const float *features, int feat_stride, short *pcm, int n_frames);
+/* Device-pointer synthesis: same layouts in device memory of the batch's device; only enqueues on
+ * `hip_stream` (a hipStream_t; NULL = the batch's own stream).  lpcnet_batch_sync() waits. */
+LPCNET_EXPORT int lpcnet_batch_synthesize_device(LPCNetBatch *b, const float *d_features, int feat_stride, short *d_pcm,
+                                                 int n_frames, void *hip_stream);
+LPCNET_EXPORT int lpcnet_batch_sync(LPCNetBatch *b);
+/* Teacher-forced variant = lpcnet_synthesize_impl(..., preload) of the reference
+ * (src/lpcnet.c:256-259,273): the first `preload` samples of every frame are read from pcm. */
+LPCNET_EXPORT int lpcnet_batch_synthesize_preload(LPCNetBatch *b, const float *features, int feat_stride, short *pcm,
+                                                  int n_frames, int preload);
+/* Codec path: packets [n_streams][n_packets][8] -> pcm [n_streams][n_packets*640] (lpcnet_decode per stream) */
+LPCNET_EXPORT int lpcnet_batch_decode(LPCNetBatch *b, const unsigned char *packets, short *pcm, int n_packets);
+
+/* State interchange with the single-stream API (PLC-style snapshot / rollback). */
+LPCNET_EXPORT int lpcnet_batch_export_state(LPCNetBatch *b, int stream, LPCNetState *st);
+LPCNET_EXPORT int lpcnet_batch_import_state(LPCNetBatch *b, int stream, const LPCNetState *st);
+
+/* Tuning / introspection */
+LPCNET_EXPORT int lpcnet_batch_set_streams_per_workgroup(LPCNetBatch *b, int s);      /* 1, 2, 4; 0 = auto */
+LPCNET_EXPORT int lpcnet_batch_get_streams_per_workgroup(const LPCNetBatch *b);
+LPCNET_EXPORT int lpcnet_batch_enable_timing(LPCNetBatch *b, int on);
+LPCNET_EXPORT int lpcnet_batch_last_timing(LPCNetBatch *b, float *ms_sample_kernel, float *ms_frame_kernels);
+LPCNET_EXPORT const char *lpcnet_batch_last_error(void);
+
+/* Parity seams used by the test-suite (SURVEY.md §7 hard part 9): the two halves of the path alone.
+ *   tail:   sample loop only, frame products given: cond_a [n][T][1152], cond_b [n][T][48], lpc [n][T][16]
+ *   frames: frame network + LPC only, products returned in the same layouts (any may be NULL) */
+LPCNET_EXPORT int lpcnet_batch_run_tail(LPCNetBatch *b, const float *cond_a, const float *cond_b, const float *lpc,
+                                        short *pcm, int n_frames, int preload);
+LPCNET_EXPORT int lpcnet_batch_run_frames(LPCNetBatch *b, const float *features, int feat_stride,
+                                          float *cond_a, float *cond_b, float *lpc, int n_frames);
+/* raw per-stream state record (layout = struct lpcn_stream_state in lpcnet_amd/csrc/lpcnet_engine.h) */
+LPCNET_EXPORT int lpcnet_batch_state_size(void);
+LPCNET_EXPORT int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out);
+LPCNET_EXPORT int lpcnet_batch_set_raw_state(LPCNetBatch *b, int stream, const void *in);
+LPCNET_EXPORT int lpcnet_batch_debug_trace(LPCNetBatch *b, int n_samples, float *host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,268 @@
+"""Python mirror of the C API in include/lpcnet.h + include/lpcnet_batch.h (ctypes over the
+C-ABI of liblpcnet_hip.so).  Same names and argument meaning as the reference's
+include/lpcnet.h so that tests read like the reference's own driver (src/lpcnet_demo.c:202-219,
+src/test_lpcnet.c:55-64).
+
+There is no CPU fallback: importing works anywhere, but every entry point needs the HIP library
+and a GPU, and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblpcnet_hip.so")
+
+NB_FEATURES = 20
+NB_TOTAL_FEATURES = 36
+LPCNET_FRAME_SIZE = 160
+LPCNET_COMPRESSED_SIZE = 8
+LPCNET_PACKET_SAMPLES = 640
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+_lib = None
+
+
+class LPCNetError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen liblpcnet_hip.so (built by `python -m lpcnet_amd.build`).  Raises if it is absent:
+    the product path never falls back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LPCNetError(f"{LIB_PATH} not built: run `python -m lpcnet_amd.build` (needs hipcc)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lpcnet_get_size.restype = C.c_int
+    L.lpcnet_init.argtypes = [vp]
+    L.lpcnet_reset.argtypes = [vp]
+    L.lpcnet_create.restype = vp
+    L.lpcnet_destroy.argtypes = [vp]
+    L.lpcnet_synthesize.argtypes = [vp, _f32p, _i16p, C.c_int]
+    L.lpcnet_synthesize.restype = None
+    L.lpcnet_load_model.argtypes = [vp, C.c_char_p, C.c_int]
+    L.lpcnet_decoder_get_size.restype = C.c_int
+    L.lpcnet_decoder_init.argtypes = [vp]
+    L.lpcnet_decoder_create.restype = vp
+    L.lpcnet_decoder_destroy.argtypes = [vp]
+    L.lpcnet_decode.argtypes = [vp, _u8p, _i16p]
+    L.lpcnet_hip_last_error.restype = C.c_char_p
+    L.lpcnet_hip_set_codebooks.argtypes = [_f32p] * 4
+    L.lpcnet_hip_set_codebooks.restype = None
+    L.lpcnet_hip_shutdown.restype = None
+    L.lpcnet_batch_create.argtypes = [C.c_int, C.c_int]
+    L.lpcnet_batch_create.restype = vp
+    L.lpcnet_batch_destroy.argtypes = [vp]
+    L.lpcnet_batch_streams.argtypes = [vp]
+    L.lpcnet_batch_load_model.argtypes = [vp, C.c_char_p, C.c_int]
+    L.lpcnet_batch_reset.argtypes = [vp, C.c_int, C.c_int]
+    L.lpcnet_batch_synthesize.argtypes = [vp, _f32p, C.c_int, _i16p, C.c_int]
+    L.lpcnet_batch_synthesize_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.lpcnet_batch_sync.argtypes = [vp]
+    L.lpcnet_batch_synthesize_preload.argtypes = [vp, _f32p, C.c_int, _i16p, C.c_int, C.c_int]
+    L.lpcnet_batch_decode.argtypes = [vp, _u8p, _i16p, C.c_int]
+    L.lpcnet_batch_export_state.argtypes = [vp, C.c_int, vp]
+    L.lpcnet_batch_import_state.argtypes = [vp, C.c_int, vp]
+    L.lpcnet_batch_set_streams_per_workgroup.argtypes = [vp, C.c_int]
+    L.lpcnet_batch_get_streams_per_workgroup.argtypes = [vp]
+    L.lpcnet_batch_enable_timing.argtypes = [vp, C.c_int]
+    L.lpcnet_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.lpcnet_batch_last_error.restype = C.c_char_p
+    L.lpcnet_batch_run_tail.argtypes = [vp, _f32p, _f32p, _f32p, _i16p, C.c_int, C.c_int]
+    L.lpcnet_batch_run_frames.argtypes = [vp, _f32p, C.c_int, vp, vp, vp, C.c_int]
+    L.lpcnet_batch_state_size.restype = C.c_int
+    L.lpcnet_batch_get_raw_state.argtypes = [vp, C.c_int, vp]
+    L.lpcnet_batch_set_raw_state.argtypes = [vp, C.c_int, vp]
+    L.lpcnet_batch_debug_trace.argtypes = [vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load_library().lpcnet_hip_last_error().decode()
+
+
+class StreamState(C.Structure):
+    """Raw per-stream record = struct lpcn_stream_state (lpcnet_amd/csrc/lpcnet_engine.h)."""
+    _fields_ = [("gru_a", C.c_float * 384), ("gru_b", C.c_float * 16),
+                ("conv1_mem", C.c_float * 168), ("conv2_mem", C.c_float * 256),
+                ("old_lpc", C.c_float * 32), ("last_sig", C.c_float * 16),
+                ("deemph_mem", C.c_float), ("last_exc", C.c_int32), ("frame_count", C.c_int32),
+                ("rng", C.c_uint32 * 4), ("lpc", C.c_float * 16), ("pad", C.c_int32 * 3)]
+
+
+class LPCNetState:
+    """lpcnet_create / lpcnet_load_model / lpcnet_synthesize / lpcnet_destroy (include/lpcnet.h)."""
+
+    def __init__(self, blob: bytes | None = None):
+        self.L = load_library()
+        self.p = self.L.lpcnet_create()
+        self._blob = None
+        if blob is not None:
+            self.load_model(blob)
+
+    def load_model(self, blob: bytes) -> int:
+        self._blob = blob
+        ret = self.L.lpcnet_load_model(self.p, blob, len(blob))
+        if ret != 0:
+            raise LPCNetError("lpcnet_load_model failed: " + last_error())
+        return ret
+
+    def reset(self):
+        self.L.lpcnet_reset(self.p)
+
+    def synthesize(self, features: np.ndarray, n: int = LPCNET_FRAME_SIZE) -> np.ndarray:
+        out = np.zeros(n, np.int16)
+        self.L.lpcnet_synthesize(self.p, np.ascontiguousarray(features[:NB_FEATURES], np.float32), out, n)
+        return out
+
+    def __del__(self):
+        try:
+            self.L.lpcnet_destroy(self.p)
+        except Exception:
+            pass
+
+
+class LPCNetDecState:
+    def __init__(self, blob: bytes):
+        self.L = load_library()
+        self.p = self.L.lpcnet_decoder_create()
+        self._blob = blob
+        # LPCNetDecState begins with its LPCNetState (reference: src/lpcnet_private.h:50-53)
+        if self.L.lpcnet_load_model(self.p, blob, len(blob)) != 0:
+            raise LPCNetError("lpcnet_load_model failed: " + last_error())
+
+    def decode(self, packet: np.ndarray) -> np.ndarray:
+        pcm = np.zeros(LPCNET_PACKET_SAMPLES, np.int16)
+        if self.L.lpcnet_decode(self.p, np.ascontiguousarray(packet, np.uint8), pcm) != 0:
+            raise LPCNetError("lpcnet_decode failed: " + last_error())
+        return pcm
+
+    def __del__(self):
+        try:
+            self.L.lpcnet_decoder_destroy(self.p)
+        except Exception:
+            pass
+
+
+def set_codebooks(cb1, cb2, cb3, cbd):
+    load_library().lpcnet_hip_set_codebooks(*[np.ascontiguousarray(x, np.float32).reshape(-1) for x in (cb1, cb2, cb3, cbd)])
+
+
+class LPCNetBatch:
+    """n independent streams on one GPU (include/lpcnet_batch.h)."""
+
+    def __init__(self, n_streams: int, blob: bytes, device: int = 0):
+        self.L = load_library()
+        self.n = n_streams
+        self.p = self.L.lpcnet_batch_create(n_streams, device)
+        if not self.p:
+            raise LPCNetError("lpcnet_batch_create failed: " + last_error())
+        if self.L.lpcnet_batch_load_model(self.p, blob, len(blob)) != 0:
+            err = last_error()
+            self.L.lpcnet_batch_destroy(self.p)
+            self.p = None
+            raise LPCNetError("lpcnet_batch_load_model failed: " + err)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise LPCNetError(f"{what} failed ({rc}): " + last_error())
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.lpcnet_batch_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, first=0, count=None):
+        self._chk(self.L.lpcnet_batch_reset(self.p, first, self.n - first if count is None else count), "reset")
+
+    def synthesize(self, features: np.ndarray, preload_pcm: np.ndarray | None = None, preload: int = 160) -> np.ndarray:
+        """features (n, T, stride>=20) float32 -> pcm (n, T*160) int16."""
+        n, T, stride = features.shape
+        assert n == self.n
+        f = np.ascontiguousarray(features, np.float32)
+        if preload_pcm is None:
+            pcm = np.zeros((n, T * 160), np.int16)
+            self._chk(self.L.lpcnet_batch_synthesize(self.p, f.reshape(-1), stride, pcm.reshape(-1), T), "synthesize")
+        else:
+            pcm = np.ascontiguousarray(preload_pcm, np.int16).copy()
+            self._chk(self.L.lpcnet_batch_synthesize_preload(self.p, f.reshape(-1), stride, pcm.reshape(-1), T, preload), "synthesize_preload")
+        return pcm
+
+    def synthesize_device(self, d_features_ptr: int, stride: int, d_pcm_ptr: int, n_frames: int, hip_stream: int = 0):
+        self._chk(self.L.lpcnet_batch_synthesize_device(self.p, d_features_ptr, stride, d_pcm_ptr, n_frames, hip_stream or None), "synthesize_device")
+
+    def sync(self):
+        self._chk(self.L.lpcnet_batch_sync(self.p), "sync")
+
+    def decode(self, packets: np.ndarray) -> np.ndarray:
+        n, P, _ = packets.shape
+        pcm = np.zeros((n, P * 640), np.int16)
+        self._chk(self.L.lpcnet_batch_decode(self.p, np.ascontiguousarray(packets, np.uint8).reshape(-1), pcm.reshape(-1), P), "decode")
+        return pcm
+
+    def run_tail(self, cond_a, cond_b, lpc, preload_pcm=None, preload=0) -> np.ndarray:
+        n, T, _ = cond_a.shape
+        pcm = np.zeros((n, T * 160), np.int16) if preload_pcm is None else np.ascontiguousarray(preload_pcm, np.int16).copy()
+        self._chk(self.L.lpcnet_batch_run_tail(self.p, np.ascontiguousarray(cond_a, np.float32).reshape(-1),
+                                               np.ascontiguousarray(cond_b, np.float32).reshape(-1),
+                                               np.ascontiguousarray(lpc, np.float32).reshape(-1), pcm.reshape(-1), T, preload), "run_tail")
+        return pcm
+
+    def run_frames(self, features: np.ndarray):
+        n, T, stride = features.shape
+        ca = np.zeros((n, T, 1152), np.float32)
+        cb = np.zeros((n, T, 48), np.float32)
+        lpc = np.zeros((n, T, 16), np.float32)
+        self._chk(self.L.lpcnet_batch_run_frames(self.p, np.ascontiguousarray(features, np.float32).reshape(-1), stride,
+                                                 ca.ctypes.data, cb.ctypes.data, lpc.ctypes.data, T), "run_frames")
+        return ca, cb, lpc
+
+    def get_state(self, stream: int) -> StreamState:
+        st = StreamState()
+        assert C.sizeof(st) == self.L.lpcnet_batch_state_size()
+        self._chk(self.L.lpcnet_batch_get_raw_state(self.p, stream, C.byref(st)), "get_state")
+        return st
+
+    def set_state(self, stream: int, st: StreamState):
+        self._chk(self.L.lpcnet_batch_set_raw_state(self.p, stream, C.byref(st)), "set_state")
+
+    @property
+    def streams_per_workgroup(self):
+        return self.L.lpcnet_batch_get_streams_per_workgroup(self.p)
+
+    @streams_per_workgroup.setter
+    def streams_per_workgroup(self, s):
+        self._chk(self.L.lpcnet_batch_set_streams_per_workgroup(self.p, s), "set_streams_per_workgroup")
+
+    def enable_timing(self, on=True):
+        self._chk(self.L.lpcnet_batch_enable_timing(self.p, int(on)), "enable_timing")
+
+    def last_timing(self):
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.L.lpcnet_batch_last_timing(self.p, C.byref(a), C.byref(b)), "last_timing")
+        return a.value, b.value
+
+    def debug_trace_alloc(self, n_samples):
+        self._chk(self.L.lpcnet_batch_debug_trace(self.p, n_samples, None), "debug_trace")
+
+    def debug_trace_fetch(self, n_samples):
+        out = np.zeros((n_samples, 420), np.float32)
+        self._chk(self.L.lpcnet_batch_debug_trace(self.p, n_samples, out.ctypes.data), "debug_trace")
+        return out

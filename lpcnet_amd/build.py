@@ -1,0 +1,61 @@
+"""Build liblpcnet_hip.so (HIP kernels for gfx950 + C host shell) in-tree with hipcc/gcc.
+
+    python -m lpcnet_amd.build [--force]
+
+hipcc cross-compiles gfx950 without a GPU.  The flags matter for bit-exactness:
+  -ffp-contract=off     every multiply and add is rounded separately (the reference's
+                        reproducible generic-C flavour does the same)
+  -fno-slp-vectorize    keep scalar f32 ops so the DPP quad broadcasts fold into v_mul_f32_dpp
+                        (packed v_pk_mul_f32 would need the weights duplicated in register pairs)
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liblpcnet_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+             "-fvisibility=hidden", "-I" + CSRC, "-I" + os.path.join(HERE, "..", "include")]
+C_FLAGS = ["-O2", "-fPIC", "-ffp-contract=off", "-std=gnu11", "-Wall", "-fvisibility=hidden", "-DLPCNET_BUILD",
+           "-I" + CSRC, "-I" + os.path.join(HERE, "..", "include")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    srcs += [os.path.join(HERE, "..", "include", f) for f in ("lpcnet.h", "lpcnet_batch.h")]
+    if not force and not _newer(LIB, srcs):
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    o = os.path.join(objdir, "engine.o")
+    run([HIPCC] + HIP_FLAGS + ["-c", os.path.join(CSRC, "engine.hip"), "-o", o])
+    objs.append(o)
+    for c in ("api.c", "model_pack.c"):
+        o = os.path.join(objdir, c[:-2] + ".o")
+        run(["gcc"] + C_FLAGS + ["-c", os.path.join(CSRC, c), "-o", o])
+        objs.append(o)
+    run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lm"])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,469 @@
+// Device runtime of the LPCNet HIP engine: model upload, per-batch device buffers, kernel launches.
+// Only the C ABI of lpcnet_engine.h is visible to the C host shell.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "lpcnet_engine.h"
+#include "lpcnet_tables_gen.h"
+#include "sample_kernel.hip.h"
+#include "frame_kernels.hip.h"
+
+static thread_local char g_err[512] = "";
+extern "C" const char *lpcn_last_error(void) { return g_err; }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            snprintf(g_err, sizeof(g_err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,      \
+                     hipGetErrorString(_e));                                                  \
+            return LPCN_E_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+struct lpcn_engine {
+    int device = 0;
+    int nw = 0, nw_variant = 0, nb_b = 0;
+    float lpc_gamma = 1.f;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    LpcnSampleArgs sargs{};        // model part filled at creation
+    LpcnFrameModel fmodel{};
+};
+
+struct lpcn_batch_dev {
+    lpcn_engine *e = nullptr;
+    int n = 0, max_chunk = 0, S = 0, frame_len = LPCN_FRAME_SIZE;
+    lpcn_stream_state *d_state = nullptr;
+    int *d_fc_base = nullptr;
+    float *d_cond_a = nullptr, *d_cond_b = nullptr, *d_lpc = nullptr, *d_cond = nullptr;
+    float *d_feat = nullptr;           // staging for host-pointer runs
+    short *d_pcm = nullptr;
+    size_t feat_cap = 0, pcm_cap = 0;
+    LpcnSampleArgs *d_args = nullptr;
+    float *d_dbg = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timing = false;
+    float ms_sample = 0.f, ms_frame = 0.f;
+};
+
+template <typename T>
+static int upload(lpcn_engine *e, const T **dst, const void *src, size_t count)
+{
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, count * sizeof(T) ? count * sizeof(T) : 16));
+    e->allocs.push_back(p);
+    if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T *)p;
+    return 0;
+}
+
+extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_model_host *m)
+{
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device visible: the LPCNet HIP engine has no CPU fallback");
+        return LPCN_E_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) { snprintf(g_err, sizeof(g_err), "bad device %d (have %d)", device, ndev); return LPCN_E_ARG; }
+    if (m->is_int8) { snprintf(g_err, sizeof(g_err), "int8 (DOT_PROD) blobs are not supported by the fp32 engine"); return LPCN_E_MODEL; }
+    static const int variants[] = {24, 32, 40};
+    int nwv = 0;
+    for (int v : variants) if (m->nw <= v) { nwv = v; break; }
+    if (!nwv) {
+        snprintf(g_err, sizeof(g_err), "GRU-A too dense for the register-resident kernel (needs %d items/lane, max 40)", m->nw);
+        return LPCN_E_MODEL;
+    }
+    HIP_TRY(hipSetDevice(device));
+    lpcn_engine *e = new lpcn_engine();
+    e->device = device;
+    e->nw = m->nw; e->nw_variant = nwv; e->nb_b = m->nb_b; e->lpc_gamma = m->lpc_gamma;
+    int rc = 0;
+    auto fail = [&](int code) { lpcn_engine_destroy(e); return code; };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail(LPCN_E_HIP);
+
+    LpcnSampleArgs &a = e->sargs;
+    // re-pad the item arrays from the model's nw to the compiled variant
+    {
+        std::vector<float> w((size_t)LPCN_WAVES * nwv * 64 * 4, 0.f);
+        std::vector<uint8_t> b((size_t)LPCN_WAVES * nwv * 64, 0);
+        for (int wv = 0; wv < LPCN_WAVES; ++wv)
+            for (int j = 0; j < m->nw; ++j) {
+                memcpy(&w[((size_t)wv * nwv + j) * 64 * 4], &m->pk_a_w[((size_t)wv * m->nw + j) * 64 * 4], 64 * 4 * sizeof(float));
+                memcpy(&b[((size_t)wv * nwv + j) * 64], &m->pk_a_blk[((size_t)wv * m->nw + j) * 64], 64);
+            }
+        if ((rc = upload<float4>(e, &a.a_w, w.data(), w.size() / 4))) return fail(rc);
+        if ((rc = upload<uint8_t>(e, &a.a_blk, b.data(), b.size()))) return fail(rc);
+    }
+    int bound[LPCN_WAVES * 4], allh[LPCN_WAVES * 3];
+    for (int wv = 0; wv < LPCN_WAVES; ++wv) {
+        for (int k = 0; k < 4; ++k) bound[wv * 4 + k] = m->pk_a_bound[wv][k];
+        for (int k = 0; k < 3; ++k) allh[wv * 3 + k] = m->pk_a_allh[wv][k];
+        bound[wv * 4 + 3] = nwv;
+    }
+#define UP(T, field, src, count) if ((rc = upload<T>(e, &a.field, src, count))) return fail(rc)
+    UP(int, a_row, m->pk_a_row, LPCN_WAVES * 3 * 64);
+    UP(int, a_bound, bound, LPCN_WAVES * 4);
+    UP(int, a_allh, allh, LPCN_WAVES * 3);
+    UP(float, emb_sig, m->emb_sig, 256 * LPCN_ROWS_A);
+    UP(float, emb_pred, m->emb_pred, 256 * LPCN_ROWS_A);
+    UP(float, emb_exc, m->emb_exc, 256 * LPCN_ROWS_A);
+    UP(float, a_bias1, m->a_bias + LPCN_ROWS_A, LPCN_ROWS_A);
+    UP(float, a_diag, m->a_diag, LPCN_ROWS_A);
+    UP(float, b_w, m->pk_b_w, (size_t)32 * m->nb_b);
+    UP(int, b_start, m->pk_b_start, 7);
+    UP(uint8_t, b_blk, m->pk_b_blk, m->nb_b);
+    UP(float, b_rec, m->b_rec, LPCN_N_B * LPCN_ROWS_B);
+    UP(float, b_bias, m->b_bias, 2 * LPCN_ROWS_B);
+    UP(float, fc_w, m->fc_w, 256 * 2 * LPCN_N_B);
+    UP(float, fc_b, m->fc_b, 512);
+    UP(float, fc_f, m->fc_f, 512);
+    UP(float, tab_tansig, lpcn_tansig, 201);
+    UP(float, tab_ulaw2lin, lpcn_ulaw2lin_tab, 256);
+    UP(float, tab_logit, lpcn_logit_tab, 256);
+#undef UP
+    a.nb_b = m->nb_b;
+
+    LpcnFrameModel &fm = e->fmodel;
+#define UPF(field, src, count) if ((rc = upload<float>(e, &fm.field, src, count))) return fail(rc)
+    UPF(conv1_w, m->conv1_w, 3 * LPCN_FRAME_IN * LPCN_COND);
+    UPF(conv1_b, m->conv1_b, LPCN_COND);
+    UPF(conv2_w, m->conv2_w, 3 * LPCN_COND * LPCN_COND);
+    UPF(conv2_b, m->conv2_b, LPCN_COND);
+    UPF(pitch_emb, m->pitch_emb, 256 * LPCN_PITCH_EMB);
+    UPF(dense1_w, m->dense1_w, LPCN_COND * LPCN_COND);
+    UPF(dense1_b, m->dense1_b, LPCN_COND);
+    UPF(dense2_w, m->dense2_w, LPCN_COND * LPCN_COND);
+    UPF(dense2_b, m->dense2_b, LPCN_COND);
+    UPF(a_dense_w, m->a_dense_w, LPCN_COND * LPCN_ROWS_A);
+    UPF(a_dense_b, m->a_dense_b, LPCN_ROWS_A);
+    UPF(b_dense_w, m->b_dense_w, LPCN_COND * LPCN_ROWS_B);
+    UPF(b_dense_b, m->b_dense_b, LPCN_ROWS_B);
+    UPF(tab_tansig, lpcn_tansig, 201);
+    UPF(tab_idct, lpcn_idct_tab, 324);
+    UPF(tab_tw, lpcn_fft_tw, 640);
+#undef UPF
+    {
+        const short *src = lpcn_fft_bitrev;
+        if ((rc = upload<short>(e, &fm.tab_bitrev, src, 320))) return fail(rc);
+    }
+    fm.lpc_gamma = m->lpc_gamma;
+    *out = e;
+    return 0;
+}
+
+extern "C" void lpcn_engine_destroy(lpcn_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+extern "C" int lpcn_engine_device(const lpcn_engine *e) { return e->device; }
+
+// ------------------------------------------------------------------------------------ batches --
+extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n, int max_chunk)
+{
+    *out = nullptr;
+    if (!e || n <= 0 || max_chunk <= 0) { snprintf(g_err, sizeof(g_err), "bad batch arguments"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(e->device));
+    lpcn_batch_dev *b = new lpcn_batch_dev();
+    b->e = e; b->n = n; b->max_chunk = max_chunk;
+    b->S = n >= 1024 ? 4 : (n >= 512 ? 2 : 1);          // fill 256 CUs first, then interleave
+    if (n >= 4 && n < 512) b->S = 1;
+    auto fail = [&](int code) { lpcn_batch_dev_destroy(b); return code; };
+#define AL(ptr, bytes) if (hipMalloc((void **)&ptr, (bytes)) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) failed", (size_t)(bytes)); return fail(LPCN_E_HIP); }
+    AL(b->d_state, sizeof(lpcn_stream_state) * n);
+    AL(b->d_fc_base, sizeof(int) * n);
+    AL(b->d_cond_a, sizeof(float) * (size_t)n * max_chunk * LPCN_ROWS_A);
+    AL(b->d_cond_b, sizeof(float) * (size_t)n * max_chunk * LPCN_ROWS_B);
+    AL(b->d_lpc, sizeof(float) * (size_t)n * max_chunk * LPCN_LPC_ORDER);
+    AL(b->d_cond, sizeof(float) * (size_t)n * (max_chunk + 4) * LPCN_COND * 2);
+    AL(b->d_args, sizeof(LpcnSampleArgs));
+#undef AL
+    for (auto &ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) return fail(LPCN_E_HIP);
+    *out = b;
+    int rc = lpcn_batch_dev_reset(b, 0, n);
+    if (rc) return fail(rc);
+    return 0;
+}
+
+extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->e->device);
+    (void)hipStreamSynchronize(b->e->stream);
+    void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &ev : b->ev) if (ev) (void)hipEventDestroy(ev);
+    delete b;
+}
+
+// lpcnet_reset semantics (src/lpcnet.c:174-182): zero everything, last_exc = lin2ulaw(0) = 128,
+// RNG seeded from the string "LPCNet" (src/kiss99.c:34-57, evaluated on the host).
+static void host_reset_state(lpcn_stream_state *st)
+{
+    memset(st, 0, sizeof(*st));
+    st->last_exc = 128;
+    uint32_t c[4] = {362436069u, 521288629u, 123456789u, 380116160u};
+    const unsigned char d[6] = {'L', 'P', 'C', 'N', 'e', 't'};
+    c[0] ^= d[0]; c[1] ^= d[1]; c[2] ^= d[2]; c[3] ^= d[3];
+    lpcn_kiss99(c);
+    c[0] ^= d[4]; c[1] ^= d[5];
+    if (c[0] == 0 || c[0] == 0x9068FFFFu) c[0]++;
+    if (c[1] == 0 || c[1] == 0x464FFFFFu) c[1]++;
+    if (c[2] == 0) c[2]++;
+    memcpy(st->rng, c, sizeof(c));
+}
+
+extern "C" int lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count)
+{
+    if (first < 0 || count < 0 || first + count > b->n) { snprintf(g_err, sizeof(g_err), "reset range"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    std::vector<lpcn_stream_state> h(count);
+    for (auto &s : h) host_reset_state(&s);
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    HIP_TRY(hipMemcpy(b->d_state + first, h.data(), sizeof(lpcn_stream_state) * count, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int lpcn_batch_dev_get_state(lpcn_batch_dev *b, int s, lpcn_stream_state *host)
+{
+    if (s < 0 || s >= b->n) { snprintf(g_err, sizeof(g_err), "stream index"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    HIP_TRY(hipMemcpy(host, b->d_state + s, sizeof(*host), hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int lpcn_batch_dev_set_state(lpcn_batch_dev *b, int s, const lpcn_stream_state *host)
+{
+    if (s < 0 || s >= b->n) { snprintf(g_err, sizeof(g_err), "stream index"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    HIP_TRY(hipMemcpy(b->d_state + s, host, sizeof(*host), hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b) { return b->S; }
+extern "C" int lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s)
+{
+    if (s == 0) s = b->n >= 1024 ? 4 : (b->n >= 512 ? 2 : 1);
+    if (s != 1 && s != 2 && s != 4) { snprintf(g_err, sizeof(g_err), "streams per workgroup must be 1, 2 or 4"); return LPCN_E_ARG; }
+    b->S = s;
+    return 0;
+}
+extern "C" int lpcn_batch_dev_set_frame_len(lpcn_batch_dev *b, int n)
+{
+    if (n < 1 || n > LPCN_FRAME_SIZE) { snprintf(g_err, sizeof(g_err), "frame length must be 1..160"); return LPCN_E_ARG; }
+    b->frame_len = n;
+    return 0;
+}
+extern "C" int lpcn_batch_dev_enable_timing(lpcn_batch_dev *b, int on) { b->timing = on != 0; return 0; }
+extern "C" int lpcn_batch_dev_last_timing(lpcn_batch_dev *b, float *ms_sample, float *ms_frame)
+{
+    if (ms_sample) *ms_sample = b->ms_sample;
+    if (ms_frame) *ms_frame = b->ms_frame;
+    return 0;
+}
+extern "C" int lpcn_batch_dev_sync(lpcn_batch_dev *b)
+{
+    HIP_TRY(hipSetDevice(b->e->device));
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- launches -----
+template <int S, int NW>
+static int launch_sample_t(lpcn_batch_dev *b, hipStream_t st, bool dbg)
+{
+    const int lds = lpcn::Lds<S>::total(b->e->nb_b);
+    const int grid = (b->n + S - 1) / S;
+    (void)dbg;
+    auto k = lpcn::sample_kernel<S, NW>;
+    HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(LPCN_WG_THREADS), lds, st, (const LpcnSampleArgs *)b->d_args);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int S>
+static int launch_sample_s(lpcn_batch_dev *b, hipStream_t st, bool dbg)
+{
+    switch (b->e->nw_variant) {
+    case 24: return launch_sample_t<S, 24>(b, st, dbg);
+    case 32: return launch_sample_t<S, 32>(b, st, dbg);
+    default: return launch_sample_t<S, 40>(b, st, dbg);
+    }
+}
+
+// one chunk of the per-sample kernel; cond_a/cond_b/lpc for the chunk are already in the batch buffers
+static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t pcm_stride, int n_frames,
+                         int preload, bool fc_from_frames)
+{
+    LpcnSampleArgs a = b->e->sargs;
+    a.n_streams = b->n; a.n_frames = n_frames; a.preload = preload; a.frame_len = b->frame_len;
+    a.fc_advance = fc_from_frames ? 1 : 0;
+    a.cond_a = b->d_cond_a; a.cond_b = b->d_cond_b; a.lpc = b->d_lpc;
+    a.fc_base = fc_from_frames ? b->d_fc_base : nullptr;
+    a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
+    a.state = b->d_state; a.dbg = b->d_dbg;
+    HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
+    const bool dbg = b->d_dbg != nullptr;
+    switch (b->S) {
+    case 1: return launch_sample_s<1>(b, st, dbg);
+    case 2: return launch_sample_s<2>(b, st, dbg);
+    default: return launch_sample_s<4>(b, st, dbg);
+    }
+}
+
+static int launch_frames(lpcn_batch_dev *b, hipStream_t st, const float *d_feat, int feat_stride,
+                         size_t feat_stream_stride, int n_frames)
+{
+    return lpcn_launch_frame_kernels(b->e->fmodel, st, b->n, n_frames, d_feat, feat_stride, feat_stream_stride,
+                                     b->d_state, b->d_fc_base, b->d_cond, b->d_cond_a, b->d_cond_b, b->d_lpc, g_err, sizeof(g_err));
+}
+
+extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, int feat_stride,
+                                  short *d_pcm, int n_frames, int preload, void *hip_stream)
+{
+    if (n_frames <= 0 || feat_stride < LPCN_NB_FEAT || preload < 0 || preload > LPCN_FRAME_SIZE) {
+        snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(b->e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->e->stream;
+    float tf = 0.f, ts = 0.f;
+    for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
+        const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
+        if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
+        int rc = launch_frames(b, st, d_features + (size_t)f0 * feat_stride, feat_stride, (size_t)n_frames * feat_stride, nf);
+        if (rc) return rc;
+        if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
+        rc = launch_sample(b, st, d_pcm + (size_t)f0 * LPCN_FRAME_SIZE, (size_t)n_frames * LPCN_FRAME_SIZE, nf, preload, true);
+        if (rc) return rc;
+        if (b->timing) {
+            HIP_TRY(hipEventRecord(b->ev[2], st));
+            HIP_TRY(hipEventSynchronize(b->ev[2]));
+            float a = 0.f, c = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
+            tf += a; ts += c;
+        }
+    }
+    if (b->timing) { b->ms_frame = tf; b->ms_sample = ts; }
+    return 0;
+}
+
+static int ensure_staging(lpcn_batch_dev *b, size_t feat_floats, size_t pcm_samples)
+{
+    if (feat_floats > b->feat_cap) {
+        if (b->d_feat) (void)hipFree(b->d_feat);
+        b->d_feat = nullptr; b->feat_cap = 0;
+        HIP_TRY(hipMalloc((void **)&b->d_feat, feat_floats * sizeof(float)));
+        b->feat_cap = feat_floats;
+    }
+    if (pcm_samples > b->pcm_cap) {
+        if (b->d_pcm) (void)hipFree(b->d_pcm);
+        b->d_pcm = nullptr; b->pcm_cap = 0;
+        HIP_TRY(hipMalloc((void **)&b->d_pcm, pcm_samples * sizeof(short)));
+        b->pcm_cap = pcm_samples;
+    }
+    return 0;
+}
+
+extern "C" int lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features, int feat_stride,
+                                       short *pcm, int n_frames, int preload)
+{
+    if (n_frames <= 0) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    const size_t nfeat = (size_t)b->n * n_frames * feat_stride, npcm = (size_t)b->n * n_frames * LPCN_FRAME_SIZE;
+    int rc = ensure_staging(b, nfeat, npcm);
+    if (rc) return rc;
+    hipStream_t st = b->e->stream;
+    HIP_TRY(hipMemcpyAsync(b->d_feat, features, nfeat * sizeof(float), hipMemcpyHostToDevice, st));
+    if (preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pcm, npcm * sizeof(short), hipMemcpyHostToDevice, st));
+    rc = lpcn_batch_dev_run(b, b->d_feat, feat_stride, b->d_pcm, n_frames, preload, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(pcm, b->d_pcm, npcm * sizeof(short), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond_a, const float *cond_b,
+                                            const float *lpc, short *pcm, int n_frames, int preload)
+{
+    if (n_frames <= 0 || preload < 0 || preload > LPCN_FRAME_SIZE) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    const size_t npcm = (size_t)b->n * n_frames * LPCN_FRAME_SIZE;
+    int rc = ensure_staging(b, 0, npcm);
+    if (rc) return rc;
+    hipStream_t st = b->e->stream;
+    if (preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pcm, npcm * sizeof(short), hipMemcpyHostToDevice, st));
+    for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
+        const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
+        // gather the chunk [stream][f0..f0+nf) into the dense chunk buffers
+        HIP_TRY(hipMemcpy2DAsync(b->d_cond_a, (size_t)nf * LPCN_ROWS_A * 4, cond_a + (size_t)f0 * LPCN_ROWS_A, (size_t)n_frames * LPCN_ROWS_A * 4,
+                                 (size_t)nf * LPCN_ROWS_A * 4, b->n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(b->d_cond_b, (size_t)nf * LPCN_ROWS_B * 4, cond_b + (size_t)f0 * LPCN_ROWS_B, (size_t)n_frames * LPCN_ROWS_B * 4,
+                                 (size_t)nf * LPCN_ROWS_B * 4, b->n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(b->d_lpc, (size_t)nf * LPCN_LPC_ORDER * 4, lpc + (size_t)f0 * LPCN_LPC_ORDER, (size_t)n_frames * LPCN_LPC_ORDER * 4,
+                                 (size_t)nf * LPCN_LPC_ORDER * 4, b->n, hipMemcpyHostToDevice, st));
+        if (b->timing) HIP_TRY(hipEventRecord(b->ev[1], st));
+        rc = launch_sample(b, st, b->d_pcm + (size_t)f0 * LPCN_FRAME_SIZE, (size_t)n_frames * LPCN_FRAME_SIZE, nf, preload, false);
+        if (rc) return rc;
+        if (b->timing) {
+            HIP_TRY(hipEventRecord(b->ev[2], st));
+            HIP_TRY(hipEventSynchronize(b->ev[2]));
+            HIP_TRY(hipEventElapsedTime(&b->ms_sample, b->ev[1], b->ev[2]));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipMemcpyAsync(pcm, b->d_pcm, npcm * sizeof(short), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int lpcn_batch_dev_run_frames_host(lpcn_batch_dev *b, const float *features, int feat_stride,
+                                              float *cond_a, float *cond_b, float *lpc, int n_frames)
+{
+    if (n_frames <= 0 || feat_stride < LPCN_NB_FEAT) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    const size_t nfeat = (size_t)b->n * n_frames * feat_stride;
+    int rc = ensure_staging(b, nfeat, 0);
+    if (rc) return rc;
+    hipStream_t st = b->e->stream;
+    HIP_TRY(hipMemcpyAsync(b->d_feat, features, nfeat * sizeof(float), hipMemcpyHostToDevice, st));
+    for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
+        const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
+        rc = launch_frames(b, st, b->d_feat + (size_t)f0 * feat_stride, feat_stride, (size_t)n_frames * feat_stride, nf);
+        if (rc) return rc;
+        if (cond_a) HIP_TRY(hipMemcpy2DAsync(cond_a + (size_t)f0 * LPCN_ROWS_A, (size_t)n_frames * LPCN_ROWS_A * 4, b->d_cond_a, (size_t)nf * LPCN_ROWS_A * 4,
+                                             (size_t)nf * LPCN_ROWS_A * 4, b->n, hipMemcpyDeviceToHost, st));
+        if (cond_b) HIP_TRY(hipMemcpy2DAsync(cond_b + (size_t)f0 * LPCN_ROWS_B, (size_t)n_frames * LPCN_ROWS_B * 4, b->d_cond_b, (size_t)nf * LPCN_ROWS_B * 4,
+                                             (size_t)nf * LPCN_ROWS_B * 4, b->n, hipMemcpyDeviceToHost, st));
+        if (lpc) HIP_TRY(hipMemcpy2DAsync(lpc + (size_t)f0 * LPCN_LPC_ORDER, (size_t)n_frames * LPCN_LPC_ORDER * 4, b->d_lpc, (size_t)nf * LPCN_LPC_ORDER * 4,
+                                          (size_t)nf * LPCN_LPC_ORDER * 4, b->n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+// debug trace (tests only): allocate / fetch the per-sample trace of workgroup 0, stream 0
+extern "C" int lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, float *host_out)
+{
+    HIP_TRY(hipSetDevice(b->e->device));
+    if (host_out == nullptr) {
+        if (b->d_dbg) { (void)hipFree(b->d_dbg); b->d_dbg = nullptr; }
+        if (n_samples > 0) {
+            HIP_TRY(hipMalloc((void **)&b->d_dbg, sizeof(float) * (size_t)n_samples * LPCN_DBG_STRIDE));
+            HIP_TRY(hipMemset(b->d_dbg, 0, sizeof(float) * (size_t)n_samples * LPCN_DBG_STRIDE));
+        }
+        return 0;
+    }
+    if (!b->d_dbg) { snprintf(g_err, sizeof(g_err), "trace not enabled"); return LPCN_E_ARG; }
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    HIP_TRY(hipMemcpy(host_out, b->d_dbg, sizeof(float) * (size_t)n_samples * LPCN_DBG_STRIDE, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,156 @@
+/* The one header that crosses from the C host shell into the HIP device runtime.
+ * Plain C ABI: pointers, sizes and ints only.
+ *
+ * Layers:
+ *   api.c (C)          public include/lpcnet.h + include/lpcnet_batch.h entry points
+ *   model_pack.c (C)   DNNw blob -> validated host model + device-friendly packings
+ *   lpc_host.c (C)     lpc_from_cepstrum on the host (used by the single-stream shell only)
+ *   engine.hip (HIP)   device memory, uploads, kernel launches  <-- declared here
+ */
+#ifndef LPCNET_ENGINE_H
+#define LPCNET_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- fixed architecture of the default model (what the reference's generated nnet_data.h
+ *      hard-codes) ---------------------------------------------------- */
+#define LPCN_N_A        384
+#define LPCN_N_B        16
+#define LPCN_COND       128
+#define LPCN_NB_FEAT    20
+#define LPCN_PITCH_EMB  64
+#define LPCN_FRAME_IN   (LPCN_NB_FEAT + LPCN_PITCH_EMB)
+#define LPCN_LPC_ORDER  16
+#define LPCN_NB_BANDS   18
+#define LPCN_FRAME_SIZE 160
+#define LPCN_FEATURES_DELAY 2
+#define LPCN_ROWS_A     (3 * LPCN_N_A)
+#define LPCN_ROWS_B     (3 * LPCN_N_B)
+
+/* ---- sample-kernel geometry --------------------------------------------------------------
+ * One workgroup = 8 wavefronts = 512 lanes runs S interleaved streams.  GRU-A's recurrent rows
+ * are dealt to lanes in "slots" of 64 rows (8 row-groups of the 8x4 block structure); each wave
+ * owns up to LPCN_MAX_SLOTS slots and keeps their weights resident in VGPRs as `nw` items of
+ * float4 (one item = the lane's row x one 4-wide input block). */
+#define LPCN_WG_THREADS 512
+#define LPCN_WAVES      8
+#define LPCN_MAX_SLOTS  3
+
+typedef struct lpcn_model_host {
+    int is_int8;                 /* blob flavour (int8 engine not in this round)               */
+    int nb_a, nb_b;              /* 8x4 blocks in GRU-A recurrent / GRU-B input matrices       */
+    int nw;                      /* items per lane needed by the register-resident packing     */
+    float lpc_gamma;
+
+    /* plain arrays (pointers into the caller's blob, reference layouts) */
+    const float *emb_sig, *emb_pred, *emb_exc;      /* [256][1152]                             */
+    const float *a_dense_w, *a_dense_b;             /* [128][1152], [1152]                     */
+    const float *b_dense_w, *b_dense_b;             /* [128][48], [48]                         */
+    const float *conv1_w, *conv1_b, *conv2_w, *conv2_b;
+    const float *pitch_emb;                         /* [256][64]                               */
+    const float *dense1_w, *dense1_b, *dense2_w, *dense2_b;
+    const float *fc_w, *fc_b, *fc_f;                /* [256][2][16], [2][256], [2][256]        */
+    const float *a_bias, *a_diag;                   /* [2][1152], [1152]                       */
+    const float *a_w; const int *a_idx;             /* float blocks [in4][out8] + index stream */
+    const float *b_bias;                            /* [2][48]                                 */
+    const float *b_w; const int *b_idx;
+    const float *b_rec;                             /* [16][48]                                */
+
+    /* device-oriented packings built by lpcn_model_pack() (malloc'ed, owned by the model)     */
+    float   *pk_a_w;      /* [8 waves][nw][64 lanes][4]     row weights per item               */
+    uint8_t *pk_a_blk;    /* [8][nw][64]                    input block index p = pos/4        */
+    int32_t *pk_a_row;    /* [8][3 slots][64]               GRU-A row (0..1151) or -1          */
+    int32_t  pk_a_bound[LPCN_WAVES][LPCN_MAX_SLOTS + 1];    /* item index where each slot starts */
+    int32_t  pk_a_allh[LPCN_WAVES][LPCN_MAX_SLOTS];        /* 1 if every live row of the slot is a candidate-state row */
+    float   *pk_b_w;      /* GRU-B input weights re-blocked [blk][row-in-group 8][k 4] per group */
+    int32_t *pk_b_start;  /* [6 groups + 1] first block of each group in pk_b_w                */
+    uint8_t *pk_b_blk;    /* [nb_b] input block index per block                                */
+} lpcn_model_host;
+
+/* model_pack.c -------------------------------------------------------------------------------
+ * Parse + validate a DNNw blob exactly like the reference loader does
+ * (src/parse_lpcnet_weights.c:53-113, :124-220) and build the packings.  Returns 0, or -1 on a
+ * malformed / incomplete blob (same condition under which lpcnet_load_model returns -1). */
+int  lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len);
+void lpcn_model_release(lpcn_model_host *m);
+
+/* ---- per-stream state as the device keeps it (AoS, one record per stream) ------------------ */
+typedef struct lpcn_stream_state {
+    float gru_a[LPCN_N_A];
+    float gru_b[LPCN_N_B];
+    float conv1_mem[2 * LPCN_FRAME_IN];
+    float conv2_mem[2 * LPCN_COND];
+    float old_lpc[LPCN_FEATURES_DELAY][LPCN_LPC_ORDER];
+    float last_sig[LPCN_LPC_ORDER];
+    float deemph_mem;
+    int32_t last_exc;
+    int32_t frame_count;
+    uint32_t rng[4];
+    float lpc[LPCN_LPC_ORDER];          /* products of the most recent frame (for export)       */
+    int32_t pad[3];
+} lpcn_stream_state;
+
+/* ---- engine.hip ----------------------------------------------------------------------------- */
+typedef struct lpcn_engine lpcn_engine;      /* one per (process, HIP device, model)            */
+
+/* All functions return 0 on success or a negative LPCN_E_* code; the message of the last failure
+ * on the calling thread is available from lpcn_last_error(). */
+#define LPCN_E_NODEVICE  (-2)
+#define LPCN_E_HIP       (-3)
+#define LPCN_E_ARG       (-4)
+#define LPCN_E_MODEL     (-5)
+const char *lpcn_last_error(void);
+
+int  lpcn_engine_create(lpcn_engine **out, int device, const lpcn_model_host *m);
+void lpcn_engine_destroy(lpcn_engine *e);
+int  lpcn_engine_device(const lpcn_engine *e);
+
+/* Device buffers for a set of n streams processed together. */
+typedef struct lpcn_batch_dev lpcn_batch_dev;
+int  lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n_streams, int max_chunk_frames);
+void lpcn_batch_dev_destroy(lpcn_batch_dev *b);
+int  lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count);           /* lpcnet_reset   */
+int  lpcn_batch_dev_get_state(lpcn_batch_dev *b, int stream, lpcn_stream_state *host);
+int  lpcn_batch_dev_set_state(lpcn_batch_dev *b, int stream, const lpcn_stream_state *host);
+int  lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b);
+int  lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s);              /* 1,2,4 (0=auto) */
+
+/* Run n_frames frames (frame network + LPC + 160-sample loop each) for every stream.
+ *   features : [n_streams][n_frames][feat_stride] floats, only [0..19] of each frame are read
+ *   pcm      : [n_streams][n_frames*160] int16
+ *   preload  : teacher forcing, 0..160 leading samples of every frame are taken from pcm
+ *              (semantics of lpcnet_synthesize_impl, src/lpcnet.c:256-259)
+ * *_dev variants take device pointers and only enqueue work on `hip_stream` (NULL = the
+ * engine's own stream); the host variant copies in/out and synchronises. */
+int  lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, int feat_stride,
+                        short *d_pcm, int n_frames, int preload, void *hip_stream);
+int  lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features, int feat_stride,
+                             short *pcm, int n_frames, int preload);
+int  lpcn_batch_dev_sync(lpcn_batch_dev *b);
+
+/* Parity seam (SURVEY.md §7 hard part 9): run only the sample loop with caller-provided frame
+ * products (host pointers): cond_a [n][f][1152], cond_b [n][f][48], lpc [n][f][16]. */
+int  lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond_a, const float *cond_b,
+                                  const float *lpc, short *pcm, int n_frames, int preload);
+/* Frame network + LPC only (host pointers); outputs like above (any may be NULL). */
+int  lpcn_batch_dev_run_frames_host(lpcn_batch_dev *b, const float *features, int feat_stride,
+                                    float *cond_a, float *cond_b, float *lpc, int n_frames);
+
+/* Timing of the most recent run: kernel-only milliseconds measured with HIP events on the
+ * stream the kernels were launched on (sample kernel, frame kernels). */
+int  lpcn_batch_dev_last_timing(lpcn_batch_dev *b, float *ms_sample, float *ms_frame);
+int  lpcn_batch_dev_enable_timing(lpcn_batch_dev *b, int on);
+/* samples produced per frame (default 160); lpcnet_synthesize(st, f, out, N) maps to N here */
+int  lpcn_batch_dev_set_frame_len(lpcn_batch_dev *b, int n);
+/* tests only: per-sample trace of workgroup 0 / stream 0 (host_out == NULL: (re)allocate n_samples records) */
+int  lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, float *host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

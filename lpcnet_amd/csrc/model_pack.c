@@ -1,0 +1,234 @@
+/* DNNw weight blob -> validated host model + device-oriented packings.
+ *
+ * Replaces, for the HIP engine, what the reference does in src/parse_lpcnet_weights.c
+ * (parse_weights :53-77, find_array_check :84-88, find_idx_check :90-113, the *_init binders
+ * :115-221) and in the generated init_lpcnet_model(): same array names, same exact-size checks,
+ * same failure condition (-> lpcnet_load_model returns -1).  The register/LDS packings built at
+ * the end are new: they exist only because the sample loop keeps GRU-A resident in VGPRs.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "lpcnet_engine.h"
+
+typedef struct { const char *name; int size; const void *data; } blob_rec;
+
+static int blob_walk(const unsigned char *p, int len, blob_rec *out, int cap)
+{
+    int n = 0;
+    while (len > 0) {
+        int32_t h[5];                               /* magic, version, type, size, block_size */
+        if (len < 64) return -1;
+        memcpy(h, p, sizeof(h));
+        if (h[3] <= 0 || h[4] < h[3] || h[4] > len - 64) return -1;
+        if (p[63] != 0) return -1;                  /* name[43] must terminate the string      */
+        if (n == cap) return -1;
+        out[n].name = (const char *)(p + 20);
+        out[n].size = h[3];
+        out[n].data = p + 64;
+        n++;
+        p += 64 + h[4];
+        len -= 64 + h[4];
+    }
+    return n;
+}
+
+static const blob_rec *blob_find(const blob_rec *r, int n, const char *name)
+{
+    for (int i = 0; i < n; i++) if (!strcmp(r[i].name, name)) return &r[i];
+    return NULL;
+}
+
+static const void *blob_need(const blob_rec *r, int n, const char *name, size_t bytes)
+{
+    const blob_rec *e = blob_find(r, n, name);
+    return (e && (size_t)e->size == bytes) ? e->data : NULL;
+}
+
+/* index stream: per 8-row group {count, pos...}; pos multiple of 4 and pos+3 < nb_in */
+static const int *blob_need_idx(const blob_rec *r, int n, const char *name, int nb_in, int nb_out, int *total)
+{
+    const blob_rec *e = blob_find(r, n, name);
+    *total = 0;
+    if (!e) return NULL;
+    const int *idx = (const int *)e->data;
+    int remain = e->size / 4;
+    while (remain > 0) {
+        int cnt = *idx++;
+        if (cnt < 0 || remain < cnt + 1) return NULL;
+        for (int i = 0; i < cnt; i++) {
+            int pos = *idx++;
+            if (pos < 0 || pos + 3 >= nb_in || (pos & 3)) return NULL;
+        }
+        nb_out -= 8;
+        remain -= cnt + 1;
+        *total += cnt;
+    }
+    return nb_out == 0 ? (const int *)e->data : NULL;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { int group, count, first_block; const int *pos; } row_group;
+
+static int cmp_group_desc(const void *a, const void *b)
+{
+    const row_group *x = (const row_group *)a, *y = (const row_group *)b;
+    if (x->count != y->count) return y->count - x->count;
+    return x->group - y->group;
+}
+
+/* Deal GRU-A's 144 row groups (8 rows each) to the 8 waves of the sample kernel.
+ *  1. sort groups by block count, take them 8 at a time -> 18 "slots" of 64 rows whose lanes
+ *     have (nearly) equal trip counts;
+ *  2. longest-processing-time assignment of slots to waves (<= 3 slots per wave);
+ *  3. per lane and item: the 4 weights of (row, block) and the block's input index. */
+static int pack_gru_a(lpcn_model_host *m)
+{
+    enum { NG = LPCN_ROWS_A / 8, NSLOT = NG / 8 };
+    row_group g[NG];
+    const int *idx = m->a_idx;
+    int blk = 0;
+    for (int i = 0; i < NG; i++) {
+        g[i].group = i; g[i].count = *idx++; g[i].pos = idx; g[i].first_block = blk;
+        idx += g[i].count; blk += g[i].count;
+    }
+    qsort(g, NG, sizeof(g[0]), cmp_group_desc);
+
+    int slot_max[NSLOT], wave_of[NSLOT], load[LPCN_WAVES] = {0}, nslots[LPCN_WAVES] = {0};
+    for (int s = 0; s < NSLOT; s++) slot_max[s] = g[8 * s].count;
+    for (int s = 0; s < NSLOT; s++) {               /* slots are already in descending order */
+        int best = -1;
+        for (int w = 0; w < LPCN_WAVES; w++)
+            if (nslots[w] < LPCN_MAX_SLOTS && (best < 0 || load[w] < load[best])) best = w;
+        wave_of[s] = best; load[best] += slot_max[s]; nslots[best]++;
+    }
+    int nw = 1;
+    for (int w = 0; w < LPCN_WAVES; w++) if (load[w] > nw) nw = load[w];
+    m->nw = nw;
+
+    m->pk_a_w   = (float *)calloc((size_t)LPCN_WAVES * nw * 64 * 4, sizeof(float));
+    m->pk_a_blk = (uint8_t *)calloc((size_t)LPCN_WAVES * nw * 64, 1);
+    m->pk_a_row = (int32_t *)malloc(sizeof(int32_t) * LPCN_WAVES * LPCN_MAX_SLOTS * 64);
+    if (!m->pk_a_w || !m->pk_a_blk || !m->pk_a_row) return -1;
+    for (int i = 0; i < LPCN_WAVES * LPCN_MAX_SLOTS * 64; i++) m->pk_a_row[i] = -1;
+
+    int fill[LPCN_WAVES] = {0}, cur[LPCN_WAVES] = {0};
+    for (int w = 0; w < LPCN_WAVES; w++)
+        for (int k = 0; k <= LPCN_MAX_SLOTS; k++) m->pk_a_bound[w][k] = 0;
+    for (int s = 0; s < NSLOT; s++) {
+        int w = wave_of[s], k = fill[w]++, j0 = cur[w], allh = 1;
+        m->pk_a_bound[w][k] = j0;
+        for (int q = 0; q < 8; q++) {
+            const row_group *rg = &g[8 * s + q];
+            if (rg->group * 8 < 2 * LPCN_N_A) allh = 0;
+            for (int r = 0; r < 8; r++) {
+                int lane = 8 * q + r;
+                m->pk_a_row[(w * LPCN_MAX_SLOTS + k) * 64 + lane] = rg->group * 8 + r;
+                for (int j = 0; j < rg->count; j++) {
+                    const float *blkw = m->a_w + (size_t)(rg->first_block + j) * 32;   /* [in 4][out 8] */
+                    size_t item = ((size_t)w * nw + (j0 + j)) * 64 + lane;
+                    for (int c = 0; c < 4; c++) m->pk_a_w[item * 4 + c] = blkw[c * 8 + r];
+                    m->pk_a_blk[item] = (uint8_t)(rg->pos[j] >> 2);
+                }
+            }
+        }
+        m->pk_a_allh[w][k] = allh;
+        cur[w] += slot_max[s];
+    }
+    for (int w = 0; w < LPCN_WAVES; w++) {
+        for (int k = fill[w]; k <= LPCN_MAX_SLOTS; k++) m->pk_a_bound[w][k] = cur[w];
+        for (int k = fill[w]; k < LPCN_MAX_SLOTS; k++) m->pk_a_allh[w][k] = 1;
+    }
+    return 0;
+}
+
+/* GRU-B input matrix: keep the block-sparse structure, re-block each 8x4 block from the blob's
+ * [in 4][out 8] to [out 8][in 4] so that one lane (= one output row) fetches its 4 weights of a
+ * block with a single 16-byte LDS read. */
+static int pack_gru_b(lpcn_model_host *m)
+{
+    enum { NG = LPCN_ROWS_B / 8 };
+    m->pk_b_w = (float *)malloc(sizeof(float) * 32 * (size_t)(m->nb_b > 0 ? m->nb_b : 1));
+    m->pk_b_blk = (uint8_t *)malloc((size_t)(m->nb_b > 0 ? m->nb_b : 1));
+    m->pk_b_start = (int32_t *)malloc(sizeof(int32_t) * (NG + 1));
+    if (!m->pk_b_w || !m->pk_b_blk || !m->pk_b_start) return -1;
+    const int *idx = m->b_idx;
+    int blk = 0;
+    for (int g = 0; g < NG; g++) {
+        int cnt = *idx++;
+        m->pk_b_start[g] = blk;
+        for (int j = 0; j < cnt; j++, blk++) {
+            const float *src = m->b_w + (size_t)blk * 32;
+            float *dst = m->pk_b_w + (size_t)blk * 32;
+            for (int r = 0; r < 8; r++)
+                for (int c = 0; c < 4; c++) dst[r * 4 + c] = src[c * 8 + r];
+            m->pk_b_blk[blk] = (uint8_t)(*idx++ >> 2);
+        }
+    }
+    m->pk_b_start[NG] = blk;
+    return 0;
+}
+
+int lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len)
+{
+    blob_rec rec[64];
+    memset(m, 0, sizeof(*m));
+    m->lpc_gamma = 1.0f;
+    if (!blob || len <= 0) return -1;
+    int n = blob_walk(blob, len, rec, 64);
+    if (n <= 0) return -1;
+
+#define NEED_F(field, name, count) \
+    do { if (!(m->field = (const float *)blob_need(rec, n, name, sizeof(float) * (size_t)(count)))) return -1; } while (0)
+    NEED_F(emb_sig,   "gru_a_embed_sig_weights",  256 * LPCN_ROWS_A);
+    NEED_F(emb_pred,  "gru_a_embed_pred_weights", 256 * LPCN_ROWS_A);
+    NEED_F(emb_exc,   "gru_a_embed_exc_weights",  256 * LPCN_ROWS_A);
+    NEED_F(a_dense_w, "gru_a_dense_feature_weights", LPCN_COND * LPCN_ROWS_A);
+    NEED_F(a_dense_b, "gru_a_dense_feature_bias", LPCN_ROWS_A);
+    NEED_F(b_dense_w, "gru_b_dense_feature_weights", LPCN_COND * LPCN_ROWS_B);
+    NEED_F(b_dense_b, "gru_b_dense_feature_bias", LPCN_ROWS_B);
+    NEED_F(conv1_w,   "feature_conv1_weights", 3 * LPCN_FRAME_IN * LPCN_COND);
+    NEED_F(conv1_b,   "feature_conv1_bias", LPCN_COND);
+    NEED_F(conv2_w,   "feature_conv2_weights", 3 * LPCN_COND * LPCN_COND);
+    NEED_F(conv2_b,   "feature_conv2_bias", LPCN_COND);
+    NEED_F(pitch_emb, "embed_pitch_weights", 256 * LPCN_PITCH_EMB);
+    NEED_F(dense1_w,  "feature_dense1_weights", LPCN_COND * LPCN_COND);
+    NEED_F(dense1_b,  "feature_dense1_bias", LPCN_COND);
+    NEED_F(dense2_w,  "feature_dense2_weights", LPCN_COND * LPCN_COND);
+    NEED_F(dense2_b,  "feature_dense2_bias", LPCN_COND);
+    NEED_F(fc_w,      "dual_fc_weights", 256 * 2 * LPCN_N_B);
+    NEED_F(fc_b,      "dual_fc_bias", 2 * 256);
+    NEED_F(fc_f,      "dual_fc_factor", 2 * 256);
+    NEED_F(a_bias,    "sparse_gru_a_bias", 2 * LPCN_ROWS_A);
+    NEED_F(a_diag,    "sparse_gru_a_recurrent_weights_diag", LPCN_ROWS_A);
+    NEED_F(b_bias,    "gru_b_bias", 2 * LPCN_ROWS_B);
+#undef NEED_F
+    /* bound by the reference's init although the float path never reads them */
+    if (!blob_need(rec, n, "embed_sig_weights", sizeof(float) * 256 * 128)) return -1;
+    if (!blob_need(rec, n, "sparse_gru_a_subias", sizeof(float) * 2 * LPCN_ROWS_A)) return -1;
+    if (!blob_need(rec, n, "gru_b_subias", sizeof(float) * 2 * LPCN_ROWS_B)) return -1;
+
+    if (!(m->a_idx = blob_need_idx(rec, n, "sparse_gru_a_recurrent_weights_idx", LPCN_N_A, LPCN_ROWS_A, &m->nb_a))) return -1;
+    if (!(m->b_idx = blob_need_idx(rec, n, "gru_b_weights_idx", LPCN_N_A, LPCN_ROWS_B, &m->nb_b))) return -1;
+
+    const blob_rec *qa = blob_find(rec, n, "sparse_gru_a_recurrent_weights");
+    if (!qa) return -1;
+    if ((size_t)qa->size == (size_t)32 * m->nb_a * sizeof(float)) m->is_int8 = 0;
+    else if (qa->size == 32 * m->nb_a) m->is_int8 = 1;
+    else return -1;
+    size_t q = m->is_int8 ? 1 : sizeof(float);
+    m->a_w = (const float *)qa->data;
+    if (!(m->b_w = (const float *)blob_need(rec, n, "gru_b_weights", q * 32 * (size_t)m->nb_b))) return -1;
+    if (!(m->b_rec = (const float *)blob_need(rec, n, "gru_b_recurrent_weights", q * LPCN_ROWS_B * LPCN_N_B))) return -1;
+
+    if (m->is_int8) return 0;                       /* valid blob; packings are float-only       */
+    if (pack_gru_a(m) || pack_gru_b(m)) { lpcn_model_release(m); return -1; }
+    return 0;
+}
+
+void lpcn_model_release(lpcn_model_host *m)
+{
+    free(m->pk_a_w); free(m->pk_a_blk); free(m->pk_a_row);
+    free(m->pk_b_w); free(m->pk_b_start); free(m->pk_b_blk);
+    m->pk_a_w = NULL; m->pk_a_blk = NULL; m->pk_a_row = NULL;
+    m->pk_b_w = NULL; m->pk_b_start = NULL; m->pk_b_blk = NULL;
+}

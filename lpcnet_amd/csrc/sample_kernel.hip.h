@@ -1,0 +1,583 @@
+// Persistent per-sample kernel of the LPCNet synthesis engine (gfx950 / CDNA4).
+//
+// Replaces the reference's per-sample path: lpcnet_synthesize_tail_impl (src/lpcnet.c:235-271)
+// -> run_sample_network (:146-167) -> compute_gru_a_input (src/nnet.c:484-491),
+// compute_sparse_gru (:410-448), compute_gruB (:326-372), sample_mdense (:163-214), and the
+// generic mat-vec kernels of src/vec.h:131-162 / :347-404.
+//
+// Arithmetic contract ("PARITY"): every output row accumulates its products in the reference's
+// generic-C order (block order, then the 4 columns of a block), each product and each sum
+// rounded separately (no FMA: build with -ffp-contract=off), table tanh.  Rows are independent,
+// so rows go to lanes and the per-row order is kept inside a lane -> results are bit-identical
+// to the reference's generic-C float build.
+//
+// Mapping (one workgroup = 8 waves = 512 lanes, S interleaved streams, S in {1,2,4}):
+//   * GRU-A recurrent weights (177 KB fp32 > 160 KB LDS) live in VGPRs for the whole launch:
+//     each lane owns <=3 output rows ("slots", dealt by model_pack.c so that the 64 rows of a
+//     wave-slot have similar block counts) as NW float4 items.
+//   * GRU-A state h (S x 384) lives in LDS as [block p][stream][4]; the 8 lanes of a row group
+//     need the same 16*S bytes, so each lane of a quad fetches ONE stream's 16 B (a single
+//     ds_read_b128 per item) and the other three streams arrive through DPP quad_perm
+//     broadcasts folded into the multiplies -- LDS traffic is 1/S of the naive scheme.
+//   * GRU-B input weights (<=73.7 KB) + recurrent matrix live in LDS; one wave per stream, one
+//     lane per output row, gates exchanged with wave shuffles (no barrier).
+//   * dual-FC tree: all 255 nodes x 2 channels are evaluated in parallel (lane = node,channel;
+//     18 weight VGPRs), a ballot per wave yields the 255 decision bits, and the stream's leader
+//     lane walks 8 levels in registers.  Speculative evaluation is exact: every node's logit is
+//     a pure function of the GRU-B state.
+//   * leader lane per stream: LPC prediction, mu-law, KISS99 thresholds, de-emphasis, PCM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lpcnet_engine.h"
+#include "lpcnet_math.h"
+
+struct LpcnSampleArgs {
+    // model (device pointers)
+    const float *emb_sig, *emb_pred, *emb_exc;      // [256][1152]
+    const float4 *a_w;                              // [8][NW][64]
+    const uint8_t *a_blk;                           // [8][NW][64]
+    const int *a_row;                               // [8][3][64]
+    const int *a_bound;                             // [8][4]
+    const int *a_allh;                              // [8][3]
+    const float *a_bias1;                           // [1152] recurrent bias row
+    const float *a_diag;                            // [1152]
+    const float *b_w;                               // [nb_b][8][4]
+    const int *b_start;                             // [7]
+    const uint8_t *b_blk;                           // [nb_b]
+    const float *b_rec;                             // [16][48]
+    const float *b_bias;                            // [2][48]
+    const float *fc_w, *fc_b, *fc_f;                // [256][2][16], [2][256], [2][256]
+    const float *tab_tansig, *tab_ulaw2lin, *tab_logit;
+    int nb_b;
+    // work
+    int n_streams, n_frames, preload, fc_advance;
+    int frame_len;                                  // samples synthesised per frame (1..160)
+    const float *cond_a;                            // [stream][frame][1152]
+    const float *cond_b;                            // [stream][frame][48]
+    const float *lpc;                               // [stream][frame][16]
+    const int *fc_base;                             // [stream] frame_count reference value
+    short *pcm;                                     // [stream] x pcm_stride samples, frame f at +f*160
+    long long pcm_stride;
+    lpcn_stream_state *state;                       // [stream]
+    float *dbg;                                     // optional per-sample trace (DBG builds)
+};
+
+#define LPCN_DBG_STRIDE 420     // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,...
+
+namespace lpcn {
+
+constexpr int NA = LPCN_N_A, NB = LPCN_N_B, RA = LPCN_ROWS_A, RB = LPCN_ROWS_B;
+
+// pointers fetched from the argument block are generic; tell the compiler they are global memory
+#define LPCN_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const LPCN_GLOBAL T *as_global(const T *p)
+{
+    return (const LPCN_GLOBAL T *)(uintptr_t)p;
+}
+template <typename T> __device__ __forceinline__ LPCN_GLOBAL T *as_global_rw(T *p)
+{
+    return (LPCN_GLOBAL T *)(uintptr_t)p;
+}
+// Loop-invariant values that hipcc would otherwise hoist out of the 160-sample loop and keep in
+// VGPRs for the whole launch; the weights need that register space.
+#define LPCN_REMAT_V(x) asm volatile("" : "+v"(x))
+#define LPCN_REMAT_S(x) asm volatile("" : "+s"(x))
+
+// ---- LDS carve-up (bytes), all offsets multiples of 16 ---------------------------------------
+template <int S> struct Lds {
+    static constexpr int HA_STRIDE = 16 * S;                       // bytes per 4-neuron block
+    static constexpr int hA     = 0;
+    static constexpr int hA_sz  = 96 * HA_STRIDE + 24 * 16;         // 16 B pad every 4 blocks
+    static constexpr int pre    = hA + hA_sz;                       // [S][1152] f32 pre-activations
+    static constexpr int inh    = pre + S * RA * 4;                 // [S][384]  input part of candidate rows
+    static constexpr int cond   = inh + S * NA * 4;                 // [S][1152] frame conditioning (GRU-A)
+    static constexpr int abias  = cond + S * RA * 4;                // [1152] recurrent bias
+    static constexpr int adiag  = abias + RA * 4;                   // [1152] diagonal recurrent weights
+    static constexpr int hB     = adiag + RA * 4;                   // [S][16]
+    static constexpr int idx    = hB + S * NB * 4;                  // [S][4] i32 (sig,pred,exc,live)
+    static constexpr int thr    = idx + S * 16;                     // [S][8] f32
+    static constexpr int mask   = thr + S * 32;                     // [S][8] u64
+    static constexpr int lead   = mask + S * 64;                    // [S][8] leader scalars (pred,deemph,exc,head,rng4)
+    static constexpr int condb  = lead + S * 32;                    // [S][48] f32
+    static constexpr int lpc    = condb + S * RB * 4;               // [S][16] f32
+    static constexpr int sig    = lpc + S * 64;                     // [S][16] f32 ring of past samples
+    static constexpr int pcmbuf = sig + S * 64;                     // [S][160] i16
+    static constexpr int tansig = pcmbuf + S * 320;                 // [204] f32
+    static constexpr int ulaw   = tansig + 816;                     // [256] f32 mu-law decode table
+    static constexpr int logit  = ulaw + 1024;                      // [256] f32 sampling thresholds
+    static constexpr int brec   = logit + 1024;                     // [16][48]
+    static constexpr int bbias  = brec + NB * RB * 4;               // [2][48]
+    static constexpr int bstart = bbias + 2 * RB * 4;               // [8] i32
+    static constexpr int bblk   = bstart + 32;                      // [576] u8
+    static constexpr int bw     = bblk + 576;                       // [nb_b][8][4] f32
+    static constexpr int total(int nb_b) { return bw + nb_b * 128; }
+    __host__ __device__ static constexpr int ha_off(int p) { return p * HA_STRIDE + (p >> 2) * 16; }
+};
+
+template <int SEL> __device__ __forceinline__ float quad_bcast(float v)
+{
+    // value held by lane (quad base + SEL); the compiler folds this into v_mul_f32_dpp
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SEL * 0x55, 0xf, 0xf, true));
+}
+
+template <int S, int NW>
+__global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
+{
+    using L = Lds<S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *const sm_pre = (float *)(smem + L::pre);
+    float *const sm_inh = (float *)(smem + L::inh);
+    float *const sm_cond = (float *)(smem + L::cond);
+    const float *const sm_abias = (const float *)(smem + L::abias);
+    const float *const sm_adiag = (const float *)(smem + L::adiag);
+    float *const sm_hB = (float *)(smem + L::hB);
+    int *const sm_idx = (int *)(smem + L::idx);
+    float *const sm_thr = (float *)(smem + L::thr);
+    unsigned long long *const sm_mask = (unsigned long long *)(smem + L::mask);
+    float *const sm_lead = (float *)(smem + L::lead);
+    float *const sm_condb = (float *)(smem + L::condb);
+    float *const sm_lpc = (float *)(smem + L::lpc);
+    float *const sm_sig = (float *)(smem + L::sig);
+    short *const sm_pcm = (short *)(smem + L::pcmbuf);
+    const float *const sm_tansig = (const float *)(smem + L::tansig);
+    const float *const sm_ulaw = (const float *)(smem + L::ulaw);
+    const float *const sm_logit = (const float *)(smem + L::logit);
+    const float *const sm_brec = (const float *)(smem + L::brec);
+    const float *const sm_bbias = (const float *)(smem + L::bbias);
+    const int *const sm_bstart = (const int *)(smem + L::bstart);
+    const unsigned char *const sm_bblk = smem + L::bblk;
+    const float *const sm_bw = (const float *)(smem + L::bw);
+
+    const int tid0 = threadIdx.x;
+    const int n_streams = Ap->n_streams, n_frames = Ap->n_frames, preload = Ap->preload, frame_len = Ap->frame_len;
+    const int s0 = blockIdx.x * S;                          // first stream of this workgroup
+    // streams past the end are computed on a clamped copy and never written back
+    auto stream_of = [&](int s) { return (s0 + s < n_streams) ? s0 + s : n_streams - 1; };
+    const int n_valid = (n_streams - s0 < S) ? n_streams - s0 : S;
+    const size_t nf = (size_t)n_frames;
+    auto *const states = as_global_rw(Ap->state);
+    const auto *const emb_sig = as_global(Ap->emb_sig);
+    const auto *const emb_pred = as_global(Ap->emb_pred);
+    const auto *const emb_exc = as_global(Ap->emb_exc);
+
+    // ------------------------------------------------------------------ resident weights ----
+    float4 w[NW];
+    uint32_t offp[(NW + 1) / 2];
+    int row[3];
+    {
+        const int lane = tid0 & 63, wave = tid0 >> 6;
+        const size_t base = (size_t)wave * NW * 64 + lane;
+        const int lane_sel = (S >= 4 ? (lane & 3) : (S == 2 ? (lane & 1) : 0)) * 16;
+        const auto *aw = (const LPCN_GLOBAL float *)as_global(Ap->a_w);
+        const auto *ab = as_global(Ap->a_blk);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const auto *v = aw + (base + (size_t)j * 64) * 4;
+            w[j] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; j += 2) {
+            const int p0 = ab[base + (size_t)j * 64];
+            const int p1 = (j + 1 < NW) ? ab[base + (size_t)(j + 1) * 64] : 0;
+            offp[j >> 1] = (uint32_t)(L::ha_off(p0) + lane_sel) | ((uint32_t)(L::ha_off(p1) + lane_sel) << 16);
+        }
+        const auto *ar = as_global(Ap->a_row);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) row[k] = ar[(wave * 3 + k) * 64 + lane];
+    }
+    int b1 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 1]);
+    int b2 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 2]);
+    const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
+
+    // ------------------------------------------------------------------ LDS residents -------
+    {
+        const int tid = tid0;
+        const int nb_b = Ap->nb_b;
+        const auto *t0 = as_global(Ap->tab_tansig), *t1 = as_global(Ap->tab_ulaw2lin), *t2 = as_global(Ap->tab_logit);
+        for (int i = tid; i < 201; i += LPCN_WG_THREADS) ((float *)(smem + L::tansig))[i] = t0[i];
+        for (int i = tid; i < 256; i += LPCN_WG_THREADS) {
+            ((float *)(smem + L::ulaw))[i] = t1[i];
+            ((float *)(smem + L::logit))[i] = t2[i];
+        }
+        const auto *ab1 = as_global(Ap->a_bias1), *adg = as_global(Ap->a_diag);
+        for (int i = tid; i < RA; i += LPCN_WG_THREADS) {
+            ((float *)(smem + L::abias))[i] = ab1[i];
+            ((float *)(smem + L::adiag))[i] = adg[i];
+        }
+        const auto *br = as_global(Ap->b_rec), *bb = as_global(Ap->b_bias);
+        for (int i = tid; i < NB * RB; i += LPCN_WG_THREADS) ((float *)(smem + L::brec))[i] = br[i];
+        for (int i = tid; i < 2 * RB; i += LPCN_WG_THREADS) ((float *)(smem + L::bbias))[i] = bb[i];
+        if (tid < 7) ((int *)(smem + L::bstart))[tid] = as_global(Ap->b_start)[tid];
+        const auto *bk = as_global(Ap->b_blk);
+        for (int i = tid; i < nb_b; i += LPCN_WG_THREADS) smem[L::bblk + i] = bk[i];
+        const auto *bw = as_global(Ap->b_w);
+        for (int i = tid; i < nb_b * 32; i += LPCN_WG_THREADS) ((float *)(smem + L::bw))[i] = bw[i];
+        for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
+            const int s = i / NA, n = i % NA;
+            *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = states[stream_of(s)].gru_a[n];
+        }
+        for (int i = tid; i < S * NB; i += LPCN_WG_THREADS) sm_hB[i] = states[stream_of(i / NB)].gru_b[i % NB];
+        // leader-lane state (lane s of wave 0 leads stream s); kept in LDS between samples
+        if (tid < S) {
+            const auto *st = &states[stream_of(tid)];
+#pragma unroll
+            for (int j = 0; j < LPCN_LPC_ORDER; ++j) sm_sig[tid * LPCN_LPC_ORDER + j] = st->last_sig[j];
+            sm_lead[tid * 8 + 0] = 0.f;                                       // pred
+            sm_lead[tid * 8 + 1] = st->deemph_mem;
+            ((int *)sm_lead)[tid * 8 + 2] = st->last_exc;
+            ((int *)sm_lead)[tid * 8 + 3] = 0;                                // ring head
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ((uint32_t *)sm_lead)[tid * 8 + 4 + j] = st->rng[j];
+        }
+    }
+    __syncthreads();
+
+    // leader: open the next sample (prediction, mu-law indices, tree thresholds)
+    auto start_sample = [&](const int ls, const bool live) {
+        int *li = (int *)sm_lead + ls * 8;
+        if (live) {
+            const int head = li[3];
+            float pred = 0.f;
+#pragma unroll
+            for (int j = 0; j < LPCN_LPC_ORDER; ++j)                              // src/lpcnet.c:252
+                pred = pred - sm_sig[ls * LPCN_LPC_ORDER + ((head + j) & 15)] * sm_lpc[ls * LPCN_LPC_ORDER + j];
+            sm_lead[ls * 8 + 0] = pred;
+            sm_idx[ls * 4 + 0] = lpcn_lin2ulaw(sm_sig[ls * LPCN_LPC_ORDER + head]);
+            sm_idx[ls * 4 + 1] = lpcn_lin2ulaw(pred);
+            sm_idx[ls * 4 + 2] = li[2];
+            // thresholds for the 8 tree levels: two KISS99 words (src/nnet.c:178-184)
+            uint32_t rng[4] = {(uint32_t)li[4], (uint32_t)li[5], (uint32_t)li[6], (uint32_t)li[7]};
+            const uint32_t r0 = lpcn_kiss99(rng), r1 = lpcn_kiss99(rng);
+            li[4] = (int)rng[0]; li[5] = (int)rng[1]; li[6] = (int)rng[2]; li[7] = (int)rng[3];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                sm_thr[ls * 8 + b] = sm_logit[(r0 >> (8 * b)) & 0xFF];
+                sm_thr[ls * 8 + 4 + b] = sm_logit[(r1 >> (8 * b)) & 0xFF];
+            }
+        } else {
+            sm_idx[ls * 4 + 0] = 0; sm_idx[ls * 4 + 1] = 0; sm_idx[ls * 4 + 2] = 0;
+        }
+        sm_idx[ls * 4 + 3] = live ? 1 : 0;
+    };
+
+    // ====================================================================== frame loop ======
+    for (int f = 0; f < n_frames; ++f) {
+        // ---- frame-rate inputs -> LDS
+        bool live = false;
+        {
+            const int tid = tid0;
+            const auto *ca = as_global(Ap->cond_a), *cb = as_global(Ap->cond_b), *lp = as_global(Ap->lpc);
+            for (int i = tid; i < S * RA; i += LPCN_WG_THREADS) {
+                const int s = i / RA, r = i % RA;
+                sm_cond[i] = ca[((size_t)stream_of(s) * nf + f) * RA + r];
+            }
+            if (tid < S * RB) sm_condb[tid] = cb[((size_t)stream_of(tid / RB) * nf + f) * RB + tid % RB];
+            if (tid < S * LPCN_LPC_ORDER)
+                sm_lpc[tid] = lp[((size_t)stream_of(tid / LPCN_LPC_ORDER) * nf + f) * LPCN_LPC_ORDER + tid % LPCN_LPC_ORDER];
+            if (tid < S) {
+                const int lstream = stream_of(tid);
+                const int fc_ref = Ap->fc_base ? as_global(Ap->fc_base)[lstream] : states[lstream].frame_count;
+                int fc = Ap->fc_advance ? fc_ref + f + 1 : fc_ref;
+                if (fc > 1000) fc = 1000;
+                live = fc > LPCN_FEATURES_DELAY;                 // src/lpcnet.c:239-243
+                if (preload > 0) {                                // teacher forcing reads the caller's samples
+                    const auto *pin = as_global(Ap->pcm) + (size_t)lstream * (size_t)Ap->pcm_stride + (size_t)f * LPCN_FRAME_SIZE;
+                    for (int i = 0; i < preload; ++i) sm_pcm[tid * LPCN_FRAME_SIZE + i] = pin[i];
+                }
+            }
+        }
+        __syncthreads();        // sm_lpc visible to the leaders
+        if (tid0 < S) start_sample(tid0, live);
+        __syncthreads();
+        int any_live = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) any_live |= sm_idx[s * 4 + 3];
+        if (!any_live) {                                     // start-up frames: zeros, no state change
+            for (int i = tid0; i < S * LPCN_FRAME_SIZE; i += LPCN_WG_THREADS) sm_pcm[i] = 0;
+            __syncthreads();
+        }
+
+        // ================================================================== sample loop ====
+        for (int smp = 0; any_live && smp < frame_len; ++smp) {
+            // ---------------------------------------------------------------- P1: GRU-A ----
+            // embedding gather for all owned rows, issued first so the L2 latency hides under slot 0
+            float ge[3][3][S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int i_sig = sm_idx[s * 4 + 0], i_pred = sm_idx[s * 4 + 1], i_exc = sm_idx[s * 4 + 2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int r = row[k] < 0 ? 0 : row[k];
+                    ge[k][0][s] = emb_sig[i_sig * RA + r];
+                    ge[k][1][s] = emb_pred[i_pred * RA + r];
+                    ge[k][2][s] = emb_exc[i_exc * RA + r];
+                }
+            }
+            float acc[S];
+            // start of a row: bias + diag*h (+ gathered input for the update/reset rows);
+            // gather sum in the reference's order ((cond + sig) + pred) + exc  (src/nnet.c:431-440, :487-489)
+            auto slot_begin = [&](const int k, const bool defer_gather) {
+                int r = row[k];
+                LPCN_REMAT_V(r);
+                r = r < 0 ? 0 : r;
+                const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
+                const bool candidate = r >= 2 * NA;
+                const float bias = sm_abias[r], diag = sm_adiag[r];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float hprev = *(const float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4);
+                    const float b = bias + diag * hprev;
+                    if (defer_gather) {
+                        acc[s] = b;
+                    } else {
+                        const float g = ((sm_cond[s * RA + r] + ge[k][0][s]) + ge[k][1][s]) + ge[k][2][s];
+                        if (candidate) sm_inh[s * NA + n] = g;
+                        acc[s] = candidate ? b : b + g;
+                    }
+                }
+            };
+            auto slot_end = [&](const int k) {
+                int r = row[k];
+                LPCN_REMAT_V(r);
+                if (r >= 0) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sm_pre[s * RA + r] = acc[s];
+                }
+            };
+            // slot 0 of most waves holds only candidate-state rows, whose chain does not start
+            // from the gathered input: do not wait for the gather there
+            slot_begin(0, allh0);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                // wave-uniform slot boundaries (a slot may be empty: b1 == b2 or b1 == 0)
+                LPCN_REMAT_S(b1);
+                if (j == b1) { slot_end(0); slot_begin(1, false); }
+                LPCN_REMAT_S(b2);
+                if (j == b2) { slot_end(1); slot_begin(2, false); }
+                uint32_t pk = offp[j >> 1];
+                LPCN_REMAT_V(pk);                            // keep the unpack inside the loop
+                const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
+                const float4 hv = *(const float4 *)(smem + L::hA + off);
+                const float hk[4] = {hv.x, hv.y, hv.z, hv.w};
+                const float wk[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if constexpr (S == 1) {
+                        acc[0] = acc[0] + wk[c] * hk[c];
+                    } else if constexpr (S == 2) {
+                        acc[0] = acc[0] + wk[c] * quad_bcast<0>(hk[c]);
+                        acc[1] = acc[1] + wk[c] * quad_bcast<1>(hk[c]);
+                    } else {
+                        acc[0] = acc[0] + wk[c] * quad_bcast<0>(hk[c]);
+                        acc[1] = acc[1] + wk[c] * quad_bcast<1>(hk[c]);
+                        acc[2] = acc[2] + wk[c] * quad_bcast<2>(hk[c]);
+                        acc[3] = acc[3] + wk[c] * quad_bcast<3>(hk[c]);
+                    }
+                }
+            }
+            // close whichever slot is still open; slots that start exactly at NW are empty rows
+            // (b1 <= b2 <= NW; items past a wave's last real item carry zero weights)
+            if (b1 >= NW) {
+                slot_end(0);
+                if (row[1] >= 0) { slot_begin(1, false); slot_end(1); }
+                if (row[2] >= 0) { slot_begin(2, false); slot_end(2); }
+            } else if (b2 >= NW) {
+                slot_end(1);
+                if (row[2] >= 0) { slot_begin(2, false); slot_end(2); }
+            } else {
+                slot_end(2);
+            }
+            if (allh0 && row[0] >= 0) {                      // deferred input part of slot 0
+                const int r = row[0], n = r - 2 * NA;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    sm_inh[s * NA + n] = ((sm_cond[s * RA + r] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
+            }
+            // update / reset rows: sigmoid in place (each lane re-reads only what it wrote)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int r = row[k];
+                LPCN_REMAT_V(r);
+                if (r >= 0 && r < 2 * NA) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        sm_pre[s * RA + r] = lpcn_sigmoid(sm_pre[s * RA + r], sm_tansig);
+                }
+            }
+            __syncthreads();                                                   // B1
+
+            int tid = tid0;
+            LPCN_REMAT_V(tid);
+            // ------------------------------------------------------------ P2: GRU-A gates --
+            if (tid < NA) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float *hp = (float *)(smem + L::hA + L::ha_off(tid >> 2) + s * 16 + (tid & 3) * 4);
+                    const float z = sm_pre[s * RA + tid], r = sm_pre[s * RA + NA + tid];
+                    const float hc = lpcn_tanh(sm_pre[s * RA + 2 * NA + tid] * r + sm_inh[s * NA + tid], sm_tansig);
+                    const float hold = *hp;
+                    const float hnew = z * hold + (1.f - z) * hc;              // src/nnet.c:447
+                    if (sm_idx[s * 4 + 3]) *hp = hnew;
+                }
+            }
+            __syncthreads();                                                   // B2
+
+            LPCN_REMAT_V(tid);
+            const int lane = tid & 63;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            // prefetch this lane's dual-FC row (node = tid>>1, channel = tid&1); it lands while GRU-B
+            // runs.  Re-fetched every sample: 18 VGPRs that must not stay live across the GRU-A loop.
+            const int node = tid >> 1, chan = tid & 1;
+            const auto *fcw_ptr = as_global(Ap->fc_w) + node * 2 * NB + chan * NB;
+            float fcw[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
+            const float fcb = as_global(Ap->fc_b)[chan * 256 + node], fcf = as_global(Ap->fc_f)[chan * 256 + node];
+            // ----------------------------------------------------- P3: GRU-B (wave = stream)
+            if (wave < S) {
+                const int s = wave;
+                const int r = lane < RB ? lane : RB - 1;
+                const int g = r >> 3, ri = r & 7;
+                float zrh = sm_bbias[r] + sm_condb[s * RB + r];               // src/nnet.c:351
+                float rec = sm_bbias[RB + r];
+                const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
+                for (int b = bbeg; b < bend; ++b) {
+                    const int p = sm_bblk[b];
+                    const float4 wv = *(const float4 *)(sm_bw + b * 32 + ri * 4);
+                    const float4 hv = *(const float4 *)(smem + L::hA + L::ha_off(p) + s * 16);
+                    zrh = zrh + wv.x * hv.x;
+                    zrh = zrh + wv.y * hv.y;
+                    zrh = zrh + wv.z * hv.z;
+                    zrh = zrh + wv.w * hv.w;
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
+                // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
+                const float sg = lpcn_sigmoid(zrh + rec, sm_tansig);
+                const float r_gate = __shfl(sg, 16 + (lane & 15));
+                const float hc = lpcn_tanh(zrh + rec * r_gate, sm_tansig);
+                const float hc_i = __shfl(hc, 32 + (lane & 15));
+                if (lane < NB) {
+                    const float hold = sm_hB[s * NB + lane];
+                    const float hnew = sg * hold + (1.f - sg) * hc_i;
+                    if (sm_idx[s * 4 + 3]) sm_hB[s * NB + lane] = hnew;
+                }
+            }
+            __syncthreads();                                                   // B3
+
+            // ------------------------------------------ P4: dual-FC tree, all nodes at once --
+            {
+                const int node_level = node > 0 ? 31 - __clz(node) : 0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float sum = fcb;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) sum = sum + fcw[j] * sm_hB[s * NB + j];   // src/nnet.c:194-199
+                    const float v = fcf * lpcn_tanh(sum, sm_tansig);
+                    // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
+                    const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+                    const float logit = v + vo;                                     // sum1 += sum2
+                    const bool bit = (sm_thr[s * 8 + node_level] < logit) && chan == 0 && node > 0;
+                    const unsigned long long m = __ballot(bit);
+                    if (lane == 0) sm_mask[s * 8 + wave] = m;
+                }
+            }
+            __syncthreads();                                                   // B4
+
+            // ------------------------------------------------ P5: leader finishes the sample --
+            if (tid < S) {
+                if (live) {
+                    const unsigned long long *mk = sm_mask + tid * 8;
+                    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
+                    const unsigned long long m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
+                    int val = 0;
+                    // node i was evaluated by wave i>>5 and sits at ballot bit 2*(i&31)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const int i = (1 << b) | val;
+                        unsigned long long mw;
+                        if (b <= 4) mw = m0;
+                        else if (b == 5) mw = m1;
+                        else if (b == 6) mw = (i & 32) ? m3 : m2;
+                        else { const int q = (i >> 5) & 3; mw = q == 0 ? m4 : (q == 1 ? m5 : (q == 2 ? m6 : m7)); }
+                        val = (val << 1) | (int)((mw >> (2 * (i & 31))) & 1ull);
+                    }
+                    int exc = val;
+                    int *li = (int *)sm_lead + tid * 8;
+                    const float pred = sm_lead[tid * 8 + 0];
+                    float deemph = sm_lead[tid * 8 + 1];
+                    int head = li[3];
+                    float pcm;
+                    if (smp < preload) {                                        // src/lpcnet.c:256-258
+                        const float x = (float)sm_pcm[tid * LPCN_FRAME_SIZE + smp];
+                        exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
+                        pcm = x - 0.85f * deemph;
+                    } else {
+                        pcm = pred + sm_ulaw[exc];                              // src/lpcnet.c:260
+                    }
+                    head = (head + 15) & 15;                                    // src/lpcnet.c:262-263
+                    sm_sig[tid * LPCN_LPC_ORDER + head] = pcm;
+                    li[3] = head;
+                    li[2] = exc;
+                    pcm = pcm + 0.85f * deemph;
+                    deemph = pcm;
+                    sm_lead[tid * 8 + 1] = deemph;
+                    if (smp >= preload) sm_pcm[tid * LPCN_FRAME_SIZE + smp] = (short)lpcn_round_pcm(pcm);
+                    if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
+                        float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
+                        d[0] = (float)exc; d[1] = (float)sm_idx[0]; d[2] = (float)sm_idx[1]; d[3] = pcm; d[4] = pred;
+                    }
+                } else {
+                    sm_pcm[tid * LPCN_FRAME_SIZE + smp] = 0;
+                }
+                if (smp + 1 < frame_len) start_sample(tid, live);
+            }
+            if (Ap->dbg && blockIdx.x == 0) {
+                float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE;
+                if (tid < NA) d[tid] = *(const float *)(smem + L::hA + L::ha_off(tid >> 2) + (tid & 3) * 4);
+                if (tid < NB) d[384 + tid] = sm_hB[tid];
+            }
+            __syncthreads();                                                   // B5
+        }
+
+        // ---- flush the frame's PCM (S*160 samples, coalesced)
+        {
+            auto *out = as_global_rw(Ap->pcm);
+            const size_t pstride = (size_t)Ap->pcm_stride;
+            for (int i = tid0; i < S * LPCN_FRAME_SIZE; i += LPCN_WG_THREADS) {
+                const int s = i / LPCN_FRAME_SIZE, k = i % LPCN_FRAME_SIZE;
+                if (s < n_valid && k < frame_len) out[(size_t)(s0 + s) * pstride + (size_t)f * LPCN_FRAME_SIZE + k] = sm_pcm[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ write state back ----
+    {
+        const int tid = tid0;
+        for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
+            const int s = i / NA, n = i % NA;
+            if (s < n_valid)
+                states[s0 + s].gru_a[n] = *(const float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4);
+        }
+        for (int i = tid; i < S * NB; i += LPCN_WG_THREADS)
+            if (i / NB < n_valid) states[s0 + i / NB].gru_b[i % NB] = sm_hB[i];
+        if (tid < n_valid) {
+            auto *st = &states[s0 + tid];
+            const int *li = (const int *)sm_lead + tid * 8;
+            const int head = li[3];
+#pragma unroll
+            for (int j = 0; j < LPCN_LPC_ORDER; ++j) {
+                st->last_sig[j] = sm_sig[tid * LPCN_LPC_ORDER + ((head + j) & 15)];
+                st->lpc[j] = sm_lpc[tid * LPCN_LPC_ORDER + j];
+            }
+            st->deemph_mem = sm_lead[tid * 8 + 1];
+            st->last_exc = li[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st->rng[j] = (uint32_t)li[4 + j];
+        }
+    }
+}
+
+}  // namespace lpcn
