@@ -68,6 +68,8 @@ LPCNET_EXPORT int lpcnet_batch_state_size(void);
 LPCNET_EXPORT int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out);
 LPCNET_EXPORT int lpcnet_batch_set_raw_state(LPCNetBatch *b, int stream, const void *in);
 LPCNET_EXPORT int lpcnet_batch_debug_trace(LPCNetBatch *b, int n_samples, float *host_out);
+/* shader-clock totals per phase of the sample kernel (workgroup 0): out == NULL enables/zeros, else 8 values */
+LPCNET_EXPORT int lpcnet_batch_profile(LPCNetBatch *b, unsigned long long *out);
 
 #ifdef __cplusplus
 }

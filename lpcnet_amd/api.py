@@ -84,6 +84,7 @@ def load_library():
     L.lpcnet_batch_get_raw_state.argtypes = [vp, C.c_int, vp]
     L.lpcnet_batch_set_raw_state.argtypes = [vp, C.c_int, vp]
     L.lpcnet_batch_debug_trace.argtypes = [vp, C.c_int, vp]
+    L.lpcnet_batch_profile.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -265,4 +266,12 @@ class LPCNetBatch:
     def debug_trace_fetch(self, n_samples):
         out = np.zeros((n_samples, 420), np.float32)
         self._chk(self.L.lpcnet_batch_debug_trace(self.p, n_samples, out.ctypes.data), "debug_trace")
+        return out
+
+    def profile_reset(self):
+        self._chk(self.L.lpcnet_batch_profile(self.p, None), "profile")
+
+    def profile_fetch(self):
+        out = np.zeros(96, np.uint64)
+        self._chk(self.L.lpcnet_batch_profile(self.p, out.ctypes.data), "profile")
         return out

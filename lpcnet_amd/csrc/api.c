@@ -406,3 +406,4 @@ int lpcnet_batch_state_size(void) { return (int)sizeof(lpcn_stream_state); }
 int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out) { NEED_MODEL(b); FWD(lpcn_batch_dev_get_state(b->dev, stream, (lpcn_stream_state *)out)); }
 int lpcnet_batch_set_raw_state(LPCNetBatch *b, int stream, const void *in) { NEED_MODEL(b); FWD(lpcn_batch_dev_set_state(b->dev, stream, (const lpcn_stream_state *)in)); }
 int lpcnet_batch_debug_trace(LPCNetBatch *b, int n_samples, float *host_out) { NEED_MODEL(b); FWD(lpcn_batch_dev_debug_trace(b->dev, n_samples, host_out)); }
+int lpcnet_batch_profile(LPCNetBatch *b, unsigned long long *out) { NEED_MODEL(b); FWD(lpcn_batch_dev_profile(b->dev, out)); }

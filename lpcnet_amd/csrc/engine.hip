@@ -44,6 +44,7 @@ struct lpcn_batch_dev {
     size_t feat_cap = 0, pcm_cap = 0;
     LpcnSampleArgs *d_args = nullptr;
     float *d_dbg = nullptr;
+    unsigned long long *d_prof = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing = false;
     float ms_sample = 0.f, ms_frame = 0.f;
@@ -70,7 +71,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     }
     if (device < 0 || device >= ndev) { snprintf(g_err, sizeof(g_err), "bad device %d (have %d)", device, ndev); return LPCN_E_ARG; }
     if (m->is_int8) { snprintf(g_err, sizeof(g_err), "int8 (DOT_PROD) blobs are not supported by the fp32 engine"); return LPCN_E_MODEL; }
-    static const int variants[] = {24, 32, 40};
+    static const int variants[] = {24, 28, 30, 32, 36, 40};
     int nwv = 0;
     for (int v : variants) if (m->nw <= v) { nwv = v; break; }
     if (!nwv) {
@@ -80,7 +81,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     HIP_TRY(hipSetDevice(device));
     lpcn_engine *e = new lpcn_engine();
     e->device = device;
-    e->nw = m->nw; e->nw_variant = nwv; e->nb_b = m->nb_b; e->lpc_gamma = m->lpc_gamma;
+    e->nw = m->nw; e->nw_variant = nwv; e->nb_b = m->nb_b_padded; e->lpc_gamma = m->lpc_gamma;
     int rc = 0;
     auto fail = [&](int code) { lpcn_engine_destroy(e); return code; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail(LPCN_E_HIP);
@@ -108,14 +109,14 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     UP(int, a_row, m->pk_a_row, LPCN_WAVES * 3 * 64);
     UP(int, a_bound, bound, LPCN_WAVES * 4);
     UP(int, a_allh, allh, LPCN_WAVES * 3);
-    UP(float, emb_sig, m->emb_sig, 256 * LPCN_ROWS_A);
-    UP(float, emb_pred, m->emb_pred, 256 * LPCN_ROWS_A);
-    UP(float, emb_exc, m->emb_exc, 256 * LPCN_ROWS_A);
+    UP(float, emb_sig, m->pk_emb[0], (size_t)256 * LPCN_WG_THREADS * 4);
+    UP(float, emb_pred, m->pk_emb[1], (size_t)256 * LPCN_WG_THREADS * 4);
+    UP(float, emb_exc, m->pk_emb[2], (size_t)256 * LPCN_WG_THREADS * 4);
     UP(float, a_bias1, m->a_bias + LPCN_ROWS_A, LPCN_ROWS_A);
     UP(float, a_diag, m->a_diag, LPCN_ROWS_A);
-    UP(float, b_w, m->pk_b_w, (size_t)32 * m->nb_b);
+    UP(float, b_w, m->pk_b_w, (size_t)32 * m->nb_b_padded);
     UP(int, b_start, m->pk_b_start, 7);
-    UP(uint8_t, b_blk, m->pk_b_blk, m->nb_b);
+    UP(uint8_t, b_blk, m->pk_b_blk, m->nb_b_padded + 4);
     UP(float, b_rec, m->b_rec, LPCN_N_B * LPCN_ROWS_B);
     UP(float, b_bias, m->b_bias, 2 * LPCN_ROWS_B);
     UP(float, fc_w, m->fc_w, 256 * 2 * LPCN_N_B);
@@ -125,7 +126,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     UP(float, tab_ulaw2lin, lpcn_ulaw2lin_tab, 256);
     UP(float, tab_logit, lpcn_logit_tab, 256);
 #undef UP
-    a.nb_b = m->nb_b;
+    a.nb_b = m->nb_b_padded;
 
     LpcnFrameModel &fm = e->fmodel;
 #define UPF(field, src, count) if ((rc = upload<float>(e, &fm.field, src, count))) return fail(rc)
@@ -197,7 +198,7 @@ extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
     if (!b) return;
     (void)hipSetDevice(b->e->device);
     (void)hipStreamSynchronize(b->e->stream);
-    void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg};
+    void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : b->ev) if (ev) (void)hipEventDestroy(ev);
     delete b;
@@ -294,7 +295,10 @@ static int launch_sample_s(lpcn_batch_dev *b, hipStream_t st, bool dbg)
 {
     switch (b->e->nw_variant) {
     case 24: return launch_sample_t<S, 24>(b, st, dbg);
+    case 28: return launch_sample_t<S, 28>(b, st, dbg);
+    case 30: return launch_sample_t<S, 30>(b, st, dbg);
     case 32: return launch_sample_t<S, 32>(b, st, dbg);
+    case 36: return launch_sample_t<S, 36>(b, st, dbg);
     default: return launch_sample_t<S, 40>(b, st, dbg);
     }
 }
@@ -309,7 +313,7 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.cond_a = b->d_cond_a; a.cond_b = b->d_cond_b; a.lpc = b->d_lpc;
     a.fc_base = fc_from_frames ? b->d_fc_base : nullptr;
     a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
-    a.state = b->d_state; a.dbg = b->d_dbg;
+    a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
     HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
     const bool dbg = b->d_dbg != nullptr;
     switch (b->S) {
@@ -465,5 +469,16 @@ extern "C" int lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, floa
     if (!b->d_dbg) { snprintf(g_err, sizeof(g_err), "trace not enabled"); return LPCN_E_ARG; }
     HIP_TRY(hipStreamSynchronize(b->e->stream));
     HIP_TRY(hipMemcpy(host_out, b->d_dbg, sizeof(float) * (size_t)n_samples * LPCN_DBG_STRIDE, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// per-phase shader-clock totals of workgroup 0 / wave 0 (out == NULL: enable + zero; else fetch 8 values)
+extern "C" int lpcn_batch_dev_profile(lpcn_batch_dev *b, unsigned long long *out)
+{
+    HIP_TRY(hipSetDevice(b->e->device));
+    if (!b->d_prof) HIP_TRY(hipMalloc((void **)&b->d_prof, 96 * sizeof(unsigned long long)));
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    if (!out) { HIP_TRY(hipMemset(b->d_prof, 0, 96 * sizeof(unsigned long long))); return 0; }
+    HIP_TRY(hipMemcpy(out, b->d_prof, 96 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }

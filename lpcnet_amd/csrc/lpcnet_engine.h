@@ -45,6 +45,7 @@ typedef struct lpcn_model_host {
     int is_int8;                 /* blob flavour (int8 engine not in this round)               */
     int nb_a, nb_b;              /* 8x4 blocks in GRU-A recurrent / GRU-B input matrices       */
     int nw;                      /* items per lane needed by the register-resident packing     */
+    int nb_b_padded;             /* GRU-B blocks after padding every row group to a multiple of 4 */
     float lpc_gamma;
 
     /* plain arrays (pointers into the caller's blob, reference layouts) */
@@ -70,6 +71,7 @@ typedef struct lpcn_model_host {
     float   *pk_b_w;      /* GRU-B input weights re-blocked [blk][row-in-group 8][k 4] per group */
     int32_t *pk_b_start;  /* [6 groups + 1] first block of each group in pk_b_w                */
     uint8_t *pk_b_blk;    /* [nb_b] input block index per block                                */
+    float   *pk_emb[3];   /* sig/pred/exc tables re-ordered to [256][512 threads][4] (3 owned rows + pad) */
 } lpcn_model_host;
 
 /* model_pack.c -------------------------------------------------------------------------------
@@ -149,6 +151,8 @@ int  lpcn_batch_dev_enable_timing(lpcn_batch_dev *b, int on);
 int  lpcn_batch_dev_set_frame_len(lpcn_batch_dev *b, int n);
 /* tests only: per-sample trace of workgroup 0 / stream 0 (host_out == NULL: (re)allocate n_samples records) */
 int  lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, float *host_out);
+/* per-phase shader-clock totals of workgroup 0 (out == NULL: enable and zero; else fetch 8 values) */
+int  lpcn_batch_dev_profile(lpcn_batch_dev *b, unsigned long long *out);
 
 #ifdef __cplusplus
 }

@@ -93,14 +93,50 @@ static int pack_gru_a(lpcn_model_host *m)
     }
     qsort(g, NG, sizeof(g[0]), cmp_group_desc);
 
-    int slot_max[NSLOT], wave_of[NSLOT], load[LPCN_WAVES] = {0}, nslots[LPCN_WAVES] = {0};
-    for (int s = 0; s < NSLOT; s++) slot_max[s] = g[8 * s].count;
-    for (int s = 0; s < NSLOT; s++) {               /* slots are already in descending order */
+    /* Slot -> wave assignment with a small cost model of the kernel (unit: items).
+     *  - candidate-only ("all-h") slots go first, one per wave: such a wave can start its item
+     *    chain before the embedding gather has landed;
+     *  - waves left without one pay ~10 items of exposed gather latency;
+     *  - every slot costs ~2 items of begin/end work;
+     *  - remaining slots: longest-processing-time on the wave cost;
+     *  - finally waves are renumbered so that the heaviest shares a SIMD with the lightest
+     *    (waves w and w+4 of a workgroup land on the same SIMD). */
+    int slot_max[NSLOT], slot_allh[NSLOT], wave_of[NSLOT], nslots[LPCN_WAVES] = {0};
+    int items[LPCN_WAVES] = {0}, cost[LPCN_WAVES] = {0};
+    for (int s = 0; s < NSLOT; s++) {
+        slot_max[s] = g[8 * s].count;
+        slot_allh[s] = 1;
+        wave_of[s] = -1;
+        for (int q = 0; q < 8; q++) if (g[8 * s + q].group * 8 < 2 * LPCN_N_A) slot_allh[s] = 0;
+    }
+    for (int s = 0; s < NSLOT; s++) {               /* pass 1: all-h slots onto empty waves */
+        if (!slot_allh[s]) continue;
+        int best = -1;
+        for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) { best = w; break; }
+        if (best < 0) continue;
+        wave_of[s] = best; nslots[best] = 1; items[best] = slot_max[s]; cost[best] = slot_max[s] + 2;
+    }
+    for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) cost[w] = 10;
+    for (int s = 0; s < NSLOT; s++) {               /* pass 2: LPT (slots are in descending order) */
+        if (wave_of[s] >= 0) continue;
         int best = -1;
         for (int w = 0; w < LPCN_WAVES; w++)
-            if (nslots[w] < LPCN_MAX_SLOTS && (best < 0 || load[w] < load[best])) best = w;
-        wave_of[s] = best; load[best] += slot_max[s]; nslots[best]++;
+            if (nslots[w] < LPCN_MAX_SLOTS && (best < 0 || cost[w] < cost[best])) best = w;
+        wave_of[s] = best; nslots[best]++; items[best] += slot_max[s]; cost[best] += slot_max[s] + 2;
     }
+    {   /* pass 3: renumber waves: rank by cost, pair rank i with rank 7-i on one SIMD */
+        int order[LPCN_WAVES], newid[LPCN_WAVES];
+        for (int w = 0; w < LPCN_WAVES; w++) order[w] = w;
+        for (int i = 0; i < LPCN_WAVES; i++)
+            for (int j = i + 1; j < LPCN_WAVES; j++)
+                if (cost[order[j]] > cost[order[i]]) { int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
+        for (int i = 0; i < LPCN_WAVES / 2; i++) { newid[order[i]] = i; newid[order[LPCN_WAVES - 1 - i]] = i + 4; }
+        int items2[LPCN_WAVES];
+        for (int w = 0; w < LPCN_WAVES; w++) items2[newid[w]] = items[w];
+        for (int w = 0; w < LPCN_WAVES; w++) items[w] = items2[w];
+        for (int s = 0; s < NSLOT; s++) wave_of[s] = newid[wave_of[s]];
+    }
+    int *load = items;
     int nw = 1;
     for (int w = 0; w < LPCN_WAVES; w++) if (load[w] > nw) nw = load[w];
     m->nw = nw;
@@ -138,6 +174,22 @@ static int pack_gru_a(lpcn_model_host *m)
         for (int k = fill[w]; k <= LPCN_MAX_SLOTS; k++) m->pk_a_bound[w][k] = cur[w];
         for (int k = fill[w]; k < LPCN_MAX_SLOTS; k++) m->pk_a_allh[w][k] = 1;
     }
+    /* Embedding tables re-ordered to the lane layout: E'[level][thread 0..511][4] holds, for the
+     * three rows a thread owns, the table entries of one mu-law level (4th float unused), so the
+     * per-sample gather is ONE 16-byte load per table and stream instead of three scattered dwords. */
+    const float *src[3] = {m->emb_sig, m->emb_pred, m->emb_exc};
+    for (int tb = 0; tb < 3; tb++) {
+        float *dst = (float *)calloc((size_t)256 * LPCN_WG_THREADS * 4, sizeof(float));
+        if (!dst) return -1;
+        for (int v = 0; v < 256; v++)
+            for (int w = 0; w < LPCN_WAVES; w++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int k = 0; k < LPCN_MAX_SLOTS; k++) {
+                        int r = m->pk_a_row[(w * LPCN_MAX_SLOTS + k) * 64 + lane];
+                        dst[((size_t)v * LPCN_WG_THREADS + w * 64 + lane) * 4 + k] = r >= 0 ? src[tb][(size_t)v * LPCN_ROWS_A + r] : 0.f;
+                    }
+        m->pk_emb[tb] = dst;
+    }
     return 0;
 }
 
@@ -147,24 +199,27 @@ static int pack_gru_a(lpcn_model_host *m)
 static int pack_gru_b(lpcn_model_host *m)
 {
     enum { NG = LPCN_ROWS_B / 8 };
-    m->pk_b_w = (float *)malloc(sizeof(float) * 32 * (size_t)(m->nb_b > 0 ? m->nb_b : 1));
-    m->pk_b_blk = (uint8_t *)malloc((size_t)(m->nb_b > 0 ? m->nb_b : 1));
+    const size_t cap = (size_t)m->nb_b + 3 * NG + 4;     /* every group padded to a multiple of 4 blocks */
+    m->pk_b_w = (float *)calloc(32 * cap, sizeof(float));
+    m->pk_b_blk = (uint8_t *)calloc(cap, 1);
     m->pk_b_start = (int32_t *)malloc(sizeof(int32_t) * (NG + 1));
     if (!m->pk_b_w || !m->pk_b_blk || !m->pk_b_start) return -1;
     const int *idx = m->b_idx;
-    int blk = 0;
+    int src_blk = 0, dst = 0;
     for (int g = 0; g < NG; g++) {
         int cnt = *idx++;
-        m->pk_b_start[g] = blk;
-        for (int j = 0; j < cnt; j++, blk++) {
-            const float *src = m->b_w + (size_t)blk * 32;
-            float *dst = m->pk_b_w + (size_t)blk * 32;
+        m->pk_b_start[g] = dst;
+        for (int j = 0; j < cnt; j++, src_blk++, dst++) {
+            const float *src = m->b_w + (size_t)src_blk * 32;
+            float *out = m->pk_b_w + (size_t)dst * 32;
             for (int r = 0; r < 8; r++)
-                for (int c = 0; c < 4; c++) dst[r * 4 + c] = src[c * 8 + r];
-            m->pk_b_blk[blk] = (uint8_t)(*idx++ >> 2);
+                for (int c = 0; c < 4; c++) out[r * 4 + c] = src[c * 8 + r];
+            m->pk_b_blk[dst] = (uint8_t)(*idx++ >> 2);
         }
+        while (dst & 3) dst++;                           /* zero-weight padding blocks (input block 0) */
     }
-    m->pk_b_start[NG] = blk;
+    m->pk_b_start[NG] = dst;
+    m->nb_b_padded = dst;
     return 0;
 }
 
@@ -229,6 +284,7 @@ void lpcn_model_release(lpcn_model_host *m)
 {
     free(m->pk_a_w); free(m->pk_a_blk); free(m->pk_a_row);
     free(m->pk_b_w); free(m->pk_b_start); free(m->pk_b_blk);
+    for (int i = 0; i < 3; i++) { free(m->pk_emb[i]); m->pk_emb[i] = NULL; }
     m->pk_a_w = NULL; m->pk_a_blk = NULL; m->pk_a_row = NULL;
     m->pk_b_w = NULL; m->pk_b_start = NULL; m->pk_b_blk = NULL;
 }

@@ -34,7 +34,7 @@
 
 struct LpcnSampleArgs {
     // model (device pointers)
-    const float *emb_sig, *emb_pred, *emb_exc;      // [256][1152]
+    const float *emb_sig, *emb_pred, *emb_exc;      // [256][512 threads][4]: lane-ordered embedding tables
     const float4 *a_w;                              // [8][NW][64]
     const uint8_t *a_blk;                           // [8][NW][64]
     const int *a_row;                               // [8][3][64]
@@ -60,7 +60,8 @@ struct LpcnSampleArgs {
     short *pcm;                                     // [stream] x pcm_stride samples, frame f at +f*160
     long long pcm_stride;
     lpcn_stream_state *state;                       // [stream]
-    float *dbg;                                     // optional per-sample trace (DBG builds)
+    float *dbg;                                     // optional per-sample trace (tests)
+    unsigned long long *prof;                       // optional: [8] shader-clock totals per phase, workgroup 0 wave 0
 };
 
 #define LPCN_DBG_STRIDE 420     // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,...
@@ -109,9 +110,10 @@ template <int S> struct Lds {
     static constexpr int brec   = logit + 1024;                     // [16][48]
     static constexpr int bbias  = brec + NB * RB * 4;               // [2][48]
     static constexpr int bstart = bbias + 2 * RB * 4;               // [8] i32
-    static constexpr int bblk   = bstart + 32;                      // [576] u8
-    static constexpr int bw     = bblk + 576;                       // [nb_b][8][4] f32
-    static constexpr int total(int nb_b) { return bw + nb_b * 128; }
+    static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
+    static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
+    static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
+    static constexpr int total(int nb_b) { return bw + (nb_b + 2) * 128; }   // +2 blocks: the GRU-B pipeline reads ahead
     __host__ __device__ static constexpr int ha_off(int p) { return p * HA_STRIDE + (p >> 2) * 16; }
 };
 
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     const float *const sm_bbias = (const float *)(smem + L::bbias);
     const int *const sm_bstart = (const int *)(smem + L::bstart);
     const unsigned char *const sm_bblk = smem + L::bblk;
+    const unsigned short *const sm_boff = (const unsigned short *)(smem + L::boff);
     const float *const sm_bw = (const float *)(smem + L::bw);
 
     const int tid0 = threadIdx.x;
@@ -210,9 +213,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         for (int i = tid; i < 2 * RB; i += LPCN_WG_THREADS) ((float *)(smem + L::bbias))[i] = bb[i];
         if (tid < 7) ((int *)(smem + L::bstart))[tid] = as_global(Ap->b_start)[tid];
         const auto *bk = as_global(Ap->b_blk);
-        for (int i = tid; i < nb_b; i += LPCN_WG_THREADS) smem[L::bblk + i] = bk[i];
+        for (int i = tid; i < 608; i += LPCN_WG_THREADS) {
+            const int pblk = i < nb_b ? bk[i] : 0;
+            smem[L::bblk + i] = (unsigned char)pblk;
+            ((unsigned short *)(smem + L::boff))[i] = (unsigned short)L::ha_off(pblk);
+        }
         const auto *bw = as_global(Ap->b_w);
-        for (int i = tid; i < nb_b * 32; i += LPCN_WG_THREADS) ((float *)(smem + L::bw))[i] = bw[i];
+        for (int i = tid; i < (nb_b + 2) * 32; i += LPCN_WG_THREADS) ((float *)(smem + L::bw))[i] = i < nb_b * 32 ? bw[i] : 0.f;
         for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
             const int s = i / NA, n = i % NA;
             *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = states[stream_of(s)].gru_a[n];
@@ -261,6 +268,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         sm_idx[ls * 4 + 3] = live ? 1 : 0;
     };
 
+    unsigned long long *const prof = Ap->prof;
+    unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool profiling = prof != nullptr && blockIdx.x == 0 && (tid0 & 63) == 0;
+#define LPCN_PROF(slot) do { if (profiling) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[slot] += now_ - tprev; tprev = now_; } } while (0)
     // ====================================================================== frame loop ======
     for (int f = 0; f < n_frames; ++f) {
         // ---- frame-rate inputs -> LDS
@@ -299,27 +310,41 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         }
 
         // ================================================================== sample loop ====
+        if (profiling) tprev = __builtin_amdgcn_s_memtime();
         for (int smp = 0; any_live && smp < frame_len; ++smp) {
             // ---------------------------------------------------------------- P1: GRU-A ----
-            // embedding gather for all owned rows, issued first so the L2 latency hides under slot 0
-            float ge[3][3][S];
+            // ---- embedding gather: one 16-byte row per table and stream holds the entries of this
+            // lane's three rows.  Register pressure is the binding constraint of this kernel (the
+            // weights own 4*NW VGPRs), so the gathered values are consumed slot by slot.
+            float ge[3][3][S];                               // sig / pred / exc entries (third set: light waves only)
+            auto gather = [&](const int k, const int set) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int i_sig = sm_idx[s * 4 + 0], i_pred = sm_idx[s * 4 + 1], i_exc = sm_idx[s * 4 + 2];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int r = row[k] < 0 ? 0 : row[k];
-                    ge[k][0][s] = emb_sig[i_sig * RA + r];
-                    ge[k][1][s] = emb_pred[i_pred * RA + r];
-                    ge[k][2][s] = emb_exc[i_exc * RA + r];
+                for (int s = 0; s < S; ++s) {
+                    const int i_sig = sm_idx[s * 4 + 0], i_pred = sm_idx[s * 4 + 1], i_exc = sm_idx[s * 4 + 2];
+                    ge[set][0][s] = emb_sig[((size_t)i_sig * LPCN_WG_THREADS + tid0) * 4 + k];
+                    ge[set][1][s] = emb_pred[((size_t)i_pred * LPCN_WG_THREADS + tid0) * 4 + k];
+                    ge[set][2][s] = emb_exc[((size_t)i_exc * LPCN_WG_THREADS + tid0) * 4 + k];
                 }
-            }
+            };
+            LPCN_PROF(5);
             float acc[S];
-            // start of a row: bias + diag*h (+ gathered input for the update/reset rows);
-            // gather sum in the reference's order ((cond + sig) + pred) + exc  (src/nnet.c:431-440, :487-489)
-            auto slot_begin = [&](const int k, const bool defer_gather) {
+            // state blocks are fetched PF items ahead of their use
+            constexpr int PF = 2;
+            float4 hq[PF + 1];
+            auto fetch_h = [&](const int j) {
+                uint32_t pk = offp[j >> 1];
+                LPCN_REMAT_V(pk);                            // keep the unpack inside the sample loop
+                const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
+                hq[j % (PF + 1)] = *(const float4 *)(smem + L::hA + off);
+            };
+            // start value of row slot k: bias + diag*h (+ gathered input for the update/reset rows),
+            // gather sum in the reference's order ((cond + sig) + pred) + exc (src/nnet.c:431-440,
+            // :487-489).  Candidate rows park the gathered input in sm_inh for the gate stage.  The
+            // value is parked in the row's own sm_pre cell until the row becomes the running one.
+            auto row_init = [&](const int k, const int set, const bool to_acc) {
                 int r = row[k];
                 LPCN_REMAT_V(r);
+                const bool live_row = r >= 0;
                 r = r < 0 ? 0 : r;
                 const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
                 const bool candidate = r >= 2 * NA;
@@ -328,16 +353,25 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 for (int s = 0; s < S; ++s) {
                     const float hprev = *(const float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4);
                     const float b = bias + diag * hprev;
-                    if (defer_gather) {
-                        acc[s] = b;
-                    } else {
-                        const float g = ((sm_cond[s * RA + r] + ge[k][0][s]) + ge[k][1][s]) + ge[k][2][s];
-                        if (candidate) sm_inh[s * NA + n] = g;
-                        acc[s] = candidate ? b : b + g;
-                    }
+                    const float g = ((sm_cond[s * RA + r] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
+                    if (candidate && live_row) sm_inh[s * NA + n] = g;
+                    const float v = candidate ? b : b + g;
+                    if (to_acc) acc[s] = v; else if (live_row) sm_pre[s * RA + r] = v;
                 }
             };
-            auto slot_end = [&](const int k) {
+            auto row_swap = [&](const int k_done, const int k_next) {   // finished row out, next row in
+                int r = row[k_done], r2 = row[k_next];
+                LPCN_REMAT_V(r);
+                LPCN_REMAT_V(r2);
+                if (r >= 0) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sm_pre[s * RA + r] = acc[s];
+                }
+                r2 = r2 < 0 ? 0 : r2;
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[s] = sm_pre[s * RA + r2];
+            };
+            auto row_store = [&](const int k) {
                 int r = row[k];
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
@@ -345,20 +379,44 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     for (int s = 0; s < S; ++s) sm_pre[s * RA + r] = acc[s];
                 }
             };
-            // slot 0 of most waves holds only candidate-state rows, whose chain does not start
-            // from the gathered input: do not wait for the gather there
-            slot_begin(0, allh0);
+            // Waves whose first slot holds only candidate rows (the big ones) start it from
+            // bias + diag*h alone and resolve the gather-dependent values slot by slot at fixed item
+            // position JSTAR (the gathers get JSTAR items to land); the light waves resolve
+            // everything up front.  jmode is wave-uniform.
+            constexpr int JSTAR = 9;
+            const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 > JSTAR) ? 1 : 0);
+            gather(1, 0);
+            gather(2, 1);
+            if (jmode == 0) {
+                gather(0, 2);
+                row_init(1, 0, false);
+                row_init(2, 1, false);
+                row_init(0, 2, true);
+            } else {
+                int r = row[0];
+                r = r < 0 ? 0 : r;
+                const int n = r - 2 * NA;
+                const float bias = sm_abias[r], diag = sm_adiag[r];
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    acc[s] = bias + diag * *(const float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
+            LPCN_REMAT_S(b1);
+            LPCN_REMAT_S(b2);
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
-                // wave-uniform slot boundaries (a slot may be empty: b1 == b2 or b1 == 0)
-                LPCN_REMAT_S(b1);
-                if (j == b1) { slot_end(0); slot_begin(1, false); }
-                LPCN_REMAT_S(b2);
-                if (j == b2) { slot_end(1); slot_begin(2, false); }
-                uint32_t pk = offp[j >> 1];
-                LPCN_REMAT_V(pk);                            // keep the unpack inside the loop
-                const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
-                const float4 hv = *(const float4 *)(smem + L::hA + off);
+                if (j == 14) LPCN_PROF(10);
+                if (j == 18) LPCN_PROF(9);       // items 14..17 (no mid-phase, usually no boundary)
+                if (j == JSTAR) { if (jmode) { row_init(1, 0, false); row_init(2, 1, false); gather(0, 0); } }
+                // wave-uniform slot boundaries (a slot may be empty: b1 == b2, or b1 == 0)
+                if (j == b1) row_swap(0, 1);
+                if (j == b2) row_swap(1, 2);
+                if (j + PF < NW) fetch_h(j + PF);
+                // one item = (this lane's row) x (one 4-wide input block) for all S streams; per output
+                // the products are added in block order, columns 0..3 (src/vec.h:355-401)
+                const float4 hv = hq[j % (PF + 1)];
                 const float hk[4] = {hv.x, hv.y, hv.z, hv.w};
                 const float wk[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
 #pragma unroll
@@ -366,62 +424,92 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     if constexpr (S == 1) {
                         acc[0] = acc[0] + wk[c] * hk[c];
                     } else if constexpr (S == 2) {
-                        acc[0] = acc[0] + wk[c] * quad_bcast<0>(hk[c]);
-                        acc[1] = acc[1] + wk[c] * quad_bcast<1>(hk[c]);
+                        const float t0 = wk[c] * quad_bcast<0>(hk[c]), t1 = wk[c] * quad_bcast<1>(hk[c]);
+                        acc[0] = acc[0] + t0; acc[1] = acc[1] + t1;
                     } else {
-                        acc[0] = acc[0] + wk[c] * quad_bcast<0>(hk[c]);
-                        acc[1] = acc[1] + wk[c] * quad_bcast<1>(hk[c]);
-                        acc[2] = acc[2] + wk[c] * quad_bcast<2>(hk[c]);
-                        acc[3] = acc[3] + wk[c] * quad_bcast<3>(hk[c]);
+                        const float t0 = wk[c] * quad_bcast<0>(hk[c]), t1 = wk[c] * quad_bcast<1>(hk[c]);
+                        const float t2 = wk[c] * quad_bcast<2>(hk[c]), t3 = wk[c] * quad_bcast<3>(hk[c]);
+                        acc[0] = acc[0] + t0; acc[1] = acc[1] + t1; acc[2] = acc[2] + t2; acc[3] = acc[3] + t3;
                     }
                 }
             }
-            // close whichever slot is still open; slots that start exactly at NW are empty rows
+            // close whichever slot is still open; slots that start exactly at NW have no items
             // (b1 <= b2 <= NW; items past a wave's last real item carry zero weights)
             if (b1 >= NW) {
-                slot_end(0);
-                if (row[1] >= 0) { slot_begin(1, false); slot_end(1); }
-                if (row[2] >= 0) { slot_begin(2, false); slot_end(2); }
+                row_swap(0, 1);
+                row_swap(1, 2);
+                row_store(2);
             } else if (b2 >= NW) {
-                slot_end(1);
-                if (row[2] >= 0) { slot_begin(2, false); slot_end(2); }
+                row_swap(1, 2);
+                row_store(2);
             } else {
-                slot_end(2);
+                row_store(2);
             }
-            if (allh0 && row[0] >= 0) {                      // deferred input part of slot 0
-                const int r = row[0], n = r - 2 * NA;
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-                    sm_inh[s * NA + n] = ((sm_cond[s * RA + r] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
-            }
-            // update / reset rows: sigmoid in place (each lane re-reads only what it wrote)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                int r = row[k];
+            if (jmode) {                                     // input part of the candidate rows of slot 0
+                int r = row[0];
                 LPCN_REMAT_V(r);
-                if (r >= 0 && r < 2 * NA) {
+                if (r >= 0) {
+                    const int n = r - 2 * NA;
 #pragma unroll
                     for (int s = 0; s < S; ++s)
-                        sm_pre[s * RA + r] = lpcn_sigmoid(sm_pre[s * RA + r], sm_tansig);
+                        sm_inh[s * NA + n] = ((sm_cond[s * RA + r] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
                 }
             }
+            LPCN_PROF(6);      // slots: begin + items + end
             __syncthreads();                                                   // B1
+            LPCN_PROF(0);
 
             int tid = tid0;
             LPCN_REMAT_V(tid);
             // ------------------------------------------------------------ P2: GRU-A gates --
-            if (tid < NA) {
+            // (a) update/reset gates: sigmoid over the 768*S pre-activations, spread over all lanes
+            {
+                constexpr int NQ = (2 * NA * S + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
+                float v[NQ];
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    float *hp = (float *)(smem + L::hA + L::ha_off(tid >> 2) + s * 16 + (tid & 3) * 4);
-                    const float z = sm_pre[s * RA + tid], r = sm_pre[s * RA + NA + tid];
-                    const float hc = lpcn_tanh(sm_pre[s * RA + 2 * NA + tid] * r + sm_inh[s * NA + tid], sm_tansig);
-                    const float hold = *hp;
-                    const float hnew = z * hold + (1.f - z) * hc;              // src/nnet.c:447
-                    if (sm_idx[s * 4 + 3]) *hp = hnew;
+                for (int q = 0; q < NQ; ++q) {
+                    const int e = tid + q * LPCN_WG_THREADS;
+                    const int s = e / (2 * NA), r = e - s * (2 * NA);
+                    v[q] = e < 2 * NA * S ? sm_pre[s * RA + r] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) v[q] = lpcn_sigmoid(v[q], sm_tansig);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int e = tid + q * LPCN_WG_THREADS;
+                    const int s = e / (2 * NA), r = e - s * (2 * NA);
+                    if (e < 2 * NA * S) sm_pre[s * RA + r] = v[q];
+                }
+            }
+            __syncthreads();
+            // (b) candidate state and blend: 384*S (neuron, stream) pairs (src/nnet.c:443-447)
+            {
+                constexpr int NQ = (NA * S + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
+                float z[NQ], a[NQ], hold[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int e = tid + q * LPCN_WG_THREADS;
+                    const int s = e / NA, i = e - s * NA;
+                    const bool ok = e < NA * S;
+                    const int ss = ok ? s : 0, ii = ok ? i : 0;
+                    z[q] = sm_pre[ss * RA + ii];
+                    const float r = sm_pre[ss * RA + NA + ii];
+                    a[q] = sm_pre[ss * RA + 2 * NA + ii] * r + sm_inh[ss * NA + ii];
+                    hold[q] = *(const float *)(smem + L::hA + L::ha_off(ii >> 2) + ss * 16 + (ii & 3) * 4);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) a[q] = lpcn_tanh(a[q], sm_tansig);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int e = tid + q * LPCN_WG_THREADS;
+                    const int s = e / NA, i = e - s * NA;
+                    const float hnew = z[q] * hold[q] + (1.f - z[q]) * a[q];   // src/nnet.c:447
+                    if (e < NA * S && sm_idx[s * 4 + 3])
+                        *(float *)(smem + L::hA + L::ha_off(i >> 2) + s * 16 + (i & 3) * 4) = hnew;
                 }
             }
             __syncthreads();                                                   // B2
+            LPCN_PROF(1);
 
             LPCN_REMAT_V(tid);
             const int lane = tid & 63;
@@ -434,6 +522,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
 #pragma unroll
             for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
             const float fcb = as_global(Ap->fc_b)[chan * 256 + node], fcf = as_global(Ap->fc_f)[chan * 256 + node];
+            LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
             if (wave < S) {
                 const int s = wave;
@@ -441,16 +530,60 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 const int g = r >> 3, ri = r & 7;
                 float zrh = sm_bbias[r] + sm_condb[s * RB + r];               // src/nnet.c:351
                 float rec = sm_bbias[RB + r];
+                // Each group's block list is padded to a multiple of 4 (zero weights) by the host.
+                // The loop is unrolled by 4 with a 4-deep register ring: block b+2 is fetched while
+                // block b feeds the dependent add chain (this phase is one wave per SIMD, so LDS
+                // latency must be hidden by software).  sm_boff holds LDS byte offsets of the input
+                // blocks, four u16 per 8-byte read.
                 const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
-                for (int b = bbeg; b < bend; ++b) {
-                    const int p = sm_bblk[b];
-                    const float4 wv = *(const float4 *)(sm_bw + b * 32 + ri * 4);
-                    const float4 hv = *(const float4 *)(smem + L::hA + L::ha_off(p) + s * 16);
-                    zrh = zrh + wv.x * hv.x;
-                    zrh = zrh + wv.y * hv.y;
-                    zrh = zrh + wv.z * hv.z;
-                    zrh = zrh + wv.w * hv.w;
+                const int nq = (bend - bbeg) >> 2;                          // groups of 4 blocks
+                const float4 *wrow = (const float4 *)sm_bw + bbeg * 8 + ri;
+                const unsigned char *hbase = smem + L::hA + s * 16;
+                const uint2 *offs = (const uint2 *)(sm_boff + bbeg);
+                // Software pipeline: loads for block b+2 are issued, products of block b+1 are formed and
+                // the running sum takes the products of block b -- pinned with scheduling barriers so
+                // that every dependent add has an independent multiply in its shadow.  Reads past the
+                // end of a group fetch valid (unused) LDS data; the host pads the arrays.
+                auto ldw = [&](int b) { return wrow[b * 8]; };
+                auto ldh = [&](unsigned o) { return *(const float4 *)(hbase + o); };
+                uint2 o_cur = offs[0], o_nxt = offs[1];
+                float4 wa = ldw(0), ha = ldh(o_cur.x & 0xFFFFu);
+                float4 wb = ldw(1), hb = ldh(o_cur.x >> 16);
+                float p0 = wa.x * ha.x, p1 = wa.y * ha.y, p2 = wa.z * ha.z, p3 = wa.w * ha.w;
+                for (int q = 0; q < nq; ++q) {
+                    const float4 *wr = wrow + q * 32;
+                    // in flight: (wa,ha) = block 4q [products p], (wb,hb) = block 4q+1
+                    { const float4 w2 = wr[16], h2 = ldh(o_cur.y & 0xFFFFu);           // block 4q+2
+                      __builtin_amdgcn_sched_barrier(0);
+                      const float q0 = wb.x * hb.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
+                      const float q1 = wb.y * hb.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
+                      const float q2 = wb.z * hb.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
+                      const float q3 = wb.w * hb.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
+                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wa = w2; ha = h2; }
+                    { const float4 w3 = wr[24], h3 = ldh(o_cur.y >> 16);               // block 4q+3
+                      __builtin_amdgcn_sched_barrier(0);
+                      const float q0 = wa.x * ha.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
+                      const float q1 = wa.y * ha.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
+                      const float q2 = wa.z * ha.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
+                      const float q3 = wa.w * ha.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
+                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wb = w3; hb = h3; }
+                    { const float4 w4 = wr[32], h4 = ldh(o_nxt.x & 0xFFFFu);           // block 4q+4
+                      __builtin_amdgcn_sched_barrier(0);
+                      const float q0 = wb.x * hb.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
+                      const float q1 = wb.y * hb.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
+                      const float q2 = wb.z * hb.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
+                      const float q3 = wb.w * hb.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
+                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wa = w4; ha = h4; }
+                    { const float4 w5 = wr[40], h5 = ldh(o_nxt.x >> 16);               // block 4q+5
+                      o_cur = o_nxt; o_nxt = offs[q + 2];
+                      __builtin_amdgcn_sched_barrier(0);
+                      const float q0 = wa.x * ha.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
+                      const float q1 = wa.y * ha.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
+                      const float q2 = wa.z * ha.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
+                      const float q3 = wa.w * ha.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
+                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wb = w5; hb = h5; }
                 }
+                LPCN_PROF(8);      // GRU-B input mat-vec
 #pragma unroll
                 for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
                 // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
@@ -465,6 +598,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 }
             }
             __syncthreads();                                                   // B3
+            LPCN_PROF(2);
 
             // ------------------------------------------ P4: dual-FC tree, all nodes at once --
             {
@@ -484,6 +618,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 }
             }
             __syncthreads();                                                   // B4
+            LPCN_PROF(3);
 
             // ------------------------------------------------ P5: leader finishes the sample --
             if (tid < S) {
@@ -539,6 +674,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 if (tid < NB) d[384 + tid] = sm_hB[tid];
             }
             __syncthreads();                                                   // B5
+            LPCN_PROF(4);
         }
 
         // ---- flush the frame's PCM (S*160 samples, coalesced)
@@ -553,6 +689,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         __syncthreads();
     }
 
+    if (profiling) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) prof[(tid0 >> 6) * 12 + i] += pt[i];
+    }
     // ------------------------------------------------------------------ write state back ----
     {
         const int tid = tid0;
