@@ -60,6 +60,7 @@ def load_library():
     L.lpcnet_hip_set_codebooks.argtypes = [_f32p] * 4
     L.lpcnet_hip_set_codebooks.restype = None
     L.lpcnet_hip_shutdown.restype = None
+    L.lpcnet_hip_check_model.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     L.lpcnet_batch_create.argtypes = [C.c_int, C.c_int]
     L.lpcnet_batch_create.restype = vp
     L.lpcnet_batch_destroy.argtypes = [vp]
@@ -87,6 +88,13 @@ def load_library():
     L.lpcnet_batch_profile.argtypes = [vp, vp]
     _lib = L
     return L
+
+
+def check_model(blob: bytes):
+    """Host-only validation of a DNNw blob: returns (code, info[6]); see include/lpcnet.h."""
+    info = (C.c_int * 6)()
+    rc = load_library().lpcnet_hip_check_model(blob, len(blob), info)
+    return rc, list(info)
 
 
 def last_error() -> str:

@@ -80,6 +80,8 @@ typedef struct lpcn_model_host {
  * malformed / incomplete blob (same condition under which lpcnet_load_model returns -1). */
 int  lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len);
 void lpcn_model_release(lpcn_model_host *m);
+/* re-expand the packings and compare them with the blob (0 = consistent) */
+int  lpcn_model_selftest(const lpcn_model_host *m);
 
 /* ---- per-stream state as the device keeps it (AoS, one record per stream) ------------------ */
 typedef struct lpcn_stream_state {

@@ -288,3 +288,90 @@ void lpcn_model_release(lpcn_model_host *m)
     m->pk_a_w = NULL; m->pk_a_blk = NULL; m->pk_a_row = NULL;
     m->pk_b_w = NULL; m->pk_b_start = NULL; m->pk_b_blk = NULL;
 }
+
+/* Consistency check of the device packings against the blob they were built from: re-expands both
+ * to dense matrices and compares them bit for bit.  Used by the CPU test-suite and by
+ * lpcnet_hip_check_model(); returns 0 when consistent, a positive code naming the first mismatch. */
+int lpcn_model_selftest(const lpcn_model_host *m)
+{
+    if (m->is_int8) return 0;
+    int rc = 0;
+    float *dense = (float *)calloc((size_t)LPCN_N_A * LPCN_ROWS_A, sizeof(float));
+    float *packed = (float *)calloc((size_t)LPCN_N_A * LPCN_ROWS_A, sizeof(float));
+    unsigned char *seen = (unsigned char *)calloc(LPCN_ROWS_A, 1);
+    if (!dense || !packed || !seen) { rc = 100; goto done; }
+    {   /* GRU-A from the blob: float blocks [in 4][out 8] */
+        const int *idx = m->a_idx;
+        const float *w = m->a_w;
+        for (int g = 0; g < LPCN_ROWS_A / 8; g++) {
+            int cnt = *idx++;
+            for (int j = 0; j < cnt; j++, w += 32) {
+                int pos = *idx++;
+                for (int c = 0; c < 4; c++)
+                    for (int r = 0; r < 8; r++) dense[(size_t)(pos + c) * LPCN_ROWS_A + g * 8 + r] = w[c * 8 + r];
+            }
+        }
+    }
+    for (int wv = 0; wv < LPCN_WAVES; wv++) {
+        for (int k = 0; k < LPCN_MAX_SLOTS; k++) {
+            int j0 = m->pk_a_bound[wv][k], j1 = m->pk_a_bound[wv][k + 1];
+            if (j0 > j1 || j1 > m->nw) { rc = 1; goto done; }
+            for (int lane = 0; lane < 64; lane++) {
+                int row = m->pk_a_row[(wv * LPCN_MAX_SLOTS + k) * 64 + lane];
+                if (row < 0) continue;
+                if (row >= LPCN_ROWS_A || seen[row]) { rc = 2; goto done; }
+                seen[row] = 1;
+                if (m->pk_a_allh[wv][k] && row < 2 * LPCN_N_A) { rc = 3; goto done; }
+                for (int j = j0; j < j1; j++) {
+                    size_t item = ((size_t)wv * m->nw + j) * 64 + lane;
+                    int p = m->pk_a_blk[item];
+                    for (int c = 0; c < 4; c++) {
+                        float v = m->pk_a_w[item * 4 + c];
+                        if (v != 0.f) packed[(size_t)(p * 4 + c) * LPCN_ROWS_A + row] = v;
+                    }
+                }
+            }
+        }
+    }
+    for (int r = 0; r < LPCN_ROWS_A; r++) if (!seen[r]) { rc = 4; goto done; }
+    if (memcmp(dense, packed, sizeof(float) * LPCN_N_A * LPCN_ROWS_A)) { rc = 5; goto done; }
+    /* lane-ordered embedding tables */
+    {
+        const float *src[3] = {m->emb_sig, m->emb_pred, m->emb_exc};
+        for (int tb = 0; tb < 3; tb++)
+            for (int v = 0; v < 256; v += 51)
+                for (int t = 0; t < LPCN_WG_THREADS; t++)
+                    for (int k = 0; k < LPCN_MAX_SLOTS; k++) {
+                        int row = m->pk_a_row[((t >> 6) * LPCN_MAX_SLOTS + k) * 64 + (t & 63)];
+                        float e = m->pk_emb[tb][((size_t)v * LPCN_WG_THREADS + t) * 4 + k];
+                        if (row >= 0 && e != src[tb][(size_t)v * LPCN_ROWS_A + row]) { rc = 6; goto done; }
+                    }
+    }
+    /* GRU-B */
+    memset(dense, 0, sizeof(float) * LPCN_N_A * LPCN_ROWS_B);
+    memset(packed, 0, sizeof(float) * LPCN_N_A * LPCN_ROWS_B);
+    {
+        const int *idx = m->b_idx;
+        const float *w = m->b_w;
+        for (int g = 0; g < LPCN_ROWS_B / 8; g++) {
+            int cnt = *idx++;
+            if ((m->pk_b_start[g] & 3) || m->pk_b_start[g + 1] - m->pk_b_start[g] < cnt) { rc = 7; goto done; }
+            for (int j = 0; j < cnt; j++, w += 32) {
+                int pos = *idx++;
+                int b = m->pk_b_start[g] + j;
+                if (m->pk_b_blk[b] != pos / 4) { rc = 8; goto done; }
+                for (int c = 0; c < 4; c++)
+                    for (int r = 0; r < 8; r++) {
+                        dense[(size_t)(pos + c) * LPCN_ROWS_B + g * 8 + r] = w[c * 8 + r];
+                        packed[(size_t)(pos + c) * LPCN_ROWS_B + g * 8 + r] = m->pk_b_w[(size_t)b * 32 + r * 4 + c];
+                    }
+            }
+            for (int b = m->pk_b_start[g] + cnt; b < m->pk_b_start[g + 1]; b++)
+                for (int q = 0; q < 32; q++) if (m->pk_b_w[(size_t)b * 32 + q] != 0.f) { rc = 9; goto done; }
+        }
+    }
+    if (memcmp(dense, packed, sizeof(float) * LPCN_N_A * LPCN_ROWS_B)) rc = 10;
+done:
+    free(dense); free(packed); free(seen);
+    return rc;
+}

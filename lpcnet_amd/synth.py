@@ -263,3 +263,14 @@ def make_features(stream_seed: int, n_frames: int) -> np.ndarray:
     f[:, NB_BANDS] = (P - 200.0) / 100.0
     f[:, NB_BANDS + 1] = 0.5 * np.sin(rng.uniform(0.01, 0.05) * t + rng.uniform(0, 2 * np.pi))
     return f.astype(np.float32)
+
+
+def make_codebooks(seed: int = 5):
+    """Synthetic VQ codebooks for the codec path (the reference's ceps_codebooks.c is a generated
+    file that is not in its tree): cb1..3 [1024][17], diff4 [4096][18]; src/lpcnet_dec.c:130-141."""
+    rng = np.random.default_rng(seed)
+    cb1 = (rng.standard_normal((1024, 17)) * 1.2).astype(np.float32)
+    cb2 = (rng.standard_normal((1024, 17)) * 0.5).astype(np.float32)
+    cb3 = (rng.standard_normal((1024, 17)) * 0.25).astype(np.float32)
+    cbd = (rng.standard_normal((4096, 18)) * 0.3).astype(np.float32)
+    return cb1, cb2, cb3, cbd

@@ -1,0 +1,54 @@
+"""Shared fixtures.  `-m "not gpu"` runs anywhere (oracle, host logic, C-ABI surface);
+`-m gpu` needs an MI355X and exercises the HIP engine through its C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from lpcnet_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "golden_v1.npz")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a HIP device (run with -m gpu on an MI355X)")
+
+
+@pytest.fixture(scope="session")
+def blob_f32():
+    return synth.blob_bytes(synth.make_model(flavour="float"))
+
+
+@pytest.fixture(scope="session")
+def blob_i8():
+    return synth.blob_bytes(synth.make_model(flavour="int8"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    if not os.path.exists(GOLDEN):
+        pytest.skip("golden fixtures missing (tools/make_golden.py)")
+    return np.load(GOLDEN)
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import orc
+    return orc.lib()
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library.  Built on demand (hipcc cross-compiles without a GPU)."""
+    from lpcnet_amd import api, build
+    build.build(verbose=False)
+    return api.load_library()
+
+
+def features(seed, n_frames):
+    return synth.make_features(seed, n_frames)

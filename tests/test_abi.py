@@ -1,0 +1,107 @@
+"""The drop-in boundary without a GPU: liblpcnet_hip.so loads, exports every symbol that
+include/lpcnet.h and include/lpcnet_batch.h declare, validates blobs like the reference loader and
+fails loudly (never silently falls back) when no HIP device is usable."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from lpcnet_amd import api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"LPCNET_EXPORT[^;(]*?\b(lpcnet_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(hip_lib):
+    names = _declared("lpcnet.h") + _declared("lpcnet_batch.h")
+    assert len(names) > 30
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    # the reference's synthesis + decoder entry points (include/lpcnet.h:67-96,160-214 of the reference)
+    for n in ("lpcnet_get_size", "lpcnet_init", "lpcnet_reset", "lpcnet_create", "lpcnet_destroy", "lpcnet_synthesize",
+              "lpcnet_load_model", "lpcnet_decoder_get_size", "lpcnet_decoder_init", "lpcnet_decoder_create",
+              "lpcnet_decoder_destroy", "lpcnet_decode"):
+        assert n in exported
+    # nothing of the internal engine ABI leaks out of the shared object
+    assert not [s for s in exported if s.startswith("lpcn_")]
+
+
+def test_state_sizes_and_init(hip_lib):
+    L = hip_lib
+    assert L.lpcnet_get_size() > 3000 and L.lpcnet_decoder_get_size() > L.lpcnet_get_size()
+    assert L.lpcnet_batch_state_size() == C.sizeof(api.StreamState)
+    buf = C.create_string_buffer(L.lpcnet_get_size())
+    assert L.lpcnet_init(buf) == 0                                   # caller-allocated state (no create/destroy)
+    st = api.LPCNetState()
+    raw = (C.c_char * L.lpcnet_get_size()).from_address(st.p)
+    s = api.StreamState.from_buffer_copy(raw.raw[8:8 + C.sizeof(api.StreamState)])
+    assert s.last_exc == 128 and s.frame_count == 0                  # lin2ulaw(0); src/lpcnet.c:180
+    assert list(s.rng) != [0, 0, 0, 0]
+
+
+def test_reset_seeds_rng_like_reference(hip_lib, golden):
+    st = api.LPCNetState()
+    raw = (C.c_char * hip_lib.lpcnet_get_size()).from_address(st.p)
+    s = api.StreamState.from_buffer_copy(raw.raw[8:8 + C.sizeof(api.StreamState)])
+    assert np.array_equal(np.array(list(s.rng), np.uint32), golden["kiss99_seeded"])
+
+
+def test_check_model_accepts_and_rejects(blob_f32, blob_i8):
+    rc, info = api.check_model(blob_f32)
+    assert rc == 0 and info[:3] == [0, 1382, 576] and info[5] == 0 and 0 < info[3] <= 40
+    rc, info = api.check_model(blob_i8)
+    assert rc == 1 and info[0] == 1
+    assert api.check_model(blob_f32[:-64])[0] == -1                 # last record truncated
+    assert api.check_model(b"")[0] == -1
+    bad = bytearray(blob_f32)
+    bad[63] = 65                                                    # record name not NUL-terminated
+    assert api.check_model(bytes(bad))[0] == -1
+    # an index stream whose positions are not multiples of 4 (src/parse_lpcnet_weights.c:104)
+    m = synth.make_model()
+    idx = m.get("gru_b_weights_idx").copy()
+    idx[1] = 2
+    m.add("gru_b_weights_idx", idx, synth.WEIGHT_TYPE_INT)
+    assert api.check_model(synth.blob_bytes(m))[0] == -1
+    # a missing array
+    m = synth.make_model()
+    del m.arrays["dual_fc_factor"]
+    assert api.check_model(synth.blob_bytes(m))[0] == -1
+
+
+@pytest.mark.parametrize("seed,dens", [(7, (0.05, 0.05, 0.2)), (8, (0.02, 0.1, 0.25)), (9, (0.1, 0.1, 0.1))])
+def test_packing_roundtrip_other_models(seed, dens):
+    blob = synth.blob_bytes(synth.make_model(seed=seed, densities=dens))
+    rc, info = api.check_model(blob)
+    assert rc == 0 and info[5] == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback(hip_lib, blob_f32):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    st = api.LPCNetState()
+    with pytest.raises(api.LPCNetError) as e:
+        st.load_model(blob_f32)
+    assert "no HIP device" in str(e.value) or "hip" in str(e.value).lower()
+    with pytest.raises(api.LPCNetError):
+        api.LPCNetBatch(4, blob_f32)
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    out = subprocess.check_output(["ldd", api.LIB_PATH], text=True)
+    assert "oracle" not in out and "lpcnet_ref" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "lpcnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text and "lpcnet_oracle.h" not in text, f

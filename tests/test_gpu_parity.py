@@ -1,0 +1,286 @@
+"""GPU parity tests: the HIP engine, called through its C ABI, against
+  * the committed golden fixtures (outputs of the real reference, generic-C float build), and
+  * the plain-C oracle on the same seeded inputs.
+Integer/index results (PCM, mu-law codes, RNG state) and -- because the engine reproduces the
+reference's accumulation order without FMA -- also every float state are compared BIT-EXACTLY
+(tolerance 0; north_star allows +-1 mu-law level, which free-running chaotic synthesis cannot use:
+SURVEY.md fact 8)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from lpcnet_amd import api, synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_run(blob, feats, with_products=False):
+    om = orc.OracleModel(blob)
+    n, T, _ = feats.shape
+    pcm = np.zeros((n, T * 160), np.int16)
+    ca = np.zeros((n, T, 1152), np.float32); cb = np.zeros((n, T, 48), np.float32); lp = np.zeros((n, T, 16), np.float32)
+    states = []
+    for s in range(n):
+        st = om.new_state()
+        for t in range(T):
+            st.L.orc_synthesize(st.p, np.ascontiguousarray(feats[s, t, :20]), pcm[s, t * 160:(t + 1) * 160], 160, 0)
+            if with_products:
+                lp[s, t], ca[s, t], cb[s, t] = st.frame_products()
+        states.append(st)
+    return (pcm, ca, cb, lp, states) if with_products else (pcm, states)
+
+
+def feats_for(seeds, T):
+    """first T frames of the 60-frame feature files the golden fixtures were made from (longer: own file)"""
+    return np.stack([synth.make_features(s, 60)[:T] if T <= 60 else synth.make_features(s, T) for s in seeds])
+
+
+@pytest.fixture(scope="module")
+def batch4(blob_f32, hip_lib):
+    b = api.LPCNetBatch(4, blob_f32)
+    yield b
+    b.close()
+
+
+def test_golden_reference_pcm_single_stream(blob_f32, golden, hip_lib):
+    """config 1: one stream on the GPU == the reference's generic-C float output, bit for bit."""
+    T = int(golden["n_frames"])
+    for seed in (1000, 1001, 1002):
+        b = api.LPCNetBatch(1, blob_f32)
+        pcm = b.synthesize(feats_for([seed], T))
+        assert np.array_equal(pcm[0], golden[f"pcm_gf_{seed}"])
+        st = b.get_state(0)
+        assert np.array_equal(np.array(st.gru_a, np.float32), golden[f"gru_a_gf_{seed}"])
+        assert np.array_equal(np.array(st.gru_b, np.float32), golden[f"gru_b_gf_{seed}"])
+        b.close()
+
+
+@pytest.mark.parametrize("S", [1, 2, 4])
+def test_multi_stream_matches_oracle_all_interleavings(blob_f32, S, hip_lib):
+    """streams-per-workgroup 1/2/4 (DPP broadcast paths), stream count not a multiple of S."""
+    n, T = 7, 9
+    feats = feats_for(range(2000, 2000 + n), T)
+    want, states = oracle_run(blob_f32, feats)
+    b = api.LPCNetBatch(n, blob_f32)
+    b.streams_per_workgroup = S
+    got = b.synthesize(feats)
+    assert np.array_equal(got, want)
+    for s in range(n):
+        st = b.get_state(s)
+        c1, c2, ga, gb = states[s].nnet_state()
+        ls, le, dm, fc, rng = states[s].signal_state()
+        assert np.array_equal(np.array(st.gru_a, np.float32), ga) and np.array_equal(np.array(st.gru_b, np.float32), gb)
+        assert np.array_equal(np.array(st.conv1_mem, np.float32), c1) and np.array_equal(np.array(st.conv2_mem, np.float32), c2)
+        assert np.array_equal(np.array(st.last_sig, np.float32), ls) and st.last_exc == le and st.frame_count == fc
+        assert np.float32(st.deemph_mem) == np.float32(dm) and np.array_equal(np.array(st.rng, np.uint32), rng)
+    b.close()
+
+
+def test_frame_network_and_lpc_seam(blob_f32, golden, batch4):
+    """frame-rate kernels alone (conv/dense/LPC incl. the 320-point FFT and double-precision pow)."""
+    T = 24
+    feats = feats_for([1000, 1001, 3000, 3001], T)
+    _, ca, cb, lp, _ = oracle_run(blob_f32, feats, with_products=True)
+    batch4.reset()
+    gca, gcb, glp = batch4.run_frames(feats)
+    assert np.array_equal(gca, ca) and np.array_equal(gcb, cb) and np.array_equal(glp, lp)
+    assert np.array_equal(glp[0], golden["lpc_gf_1000"][:T]) and np.array_equal(gcb[1], golden["condb_gf_1001"][:T])
+    assert np.array_equal(gca[0, :8], golden["conda_gf_1000_first8"])
+
+
+def test_sample_loop_seam(blob_f32, batch4):
+    """sample kernel alone on frame products supplied by the oracle (SURVEY.md §7 hard part 9)."""
+    T = 6
+    feats = feats_for([1000, 1001, 1002, 1003], T)
+    _, ca, cb, lp, _ = oracle_run(blob_f32, feats, with_products=True)
+    om = orc.OracleModel(blob_f32)
+    want = np.zeros((4, T * 160), np.int16)
+    for s in range(4):
+        o = om.new_state()
+        o.L.orc_force_frame_count(o.p, 3)
+        for t in range(T):
+            o.L.orc_synthesize_tail(o.p, ca[s, t], cb[s, t], lp[s, t], want[s, t * 160:(t + 1) * 160], 160, 0)
+    batch4.reset()
+    for s in range(4):
+        st = batch4.get_state(s)
+        st.frame_count = 3
+        batch4.set_state(s, st)
+    got = batch4.run_tail(ca, cb, lp)
+    assert np.array_equal(got, want)
+
+
+def test_streaming_calls_equal_one_call_and_chunking(blob_f32, hip_lib):
+    """state carried across calls; n_frames above the internal 100-frame chunk; single-frame calls."""
+    n, T = 2, 104
+    feats = feats_for([4000, 4001], T)
+    b = api.LPCNetBatch(n, blob_f32)
+    whole = b.synthesize(feats)
+    b.reset()
+    parts = [b.synthesize(np.ascontiguousarray(feats[:, a:z])) for a, z in ((0, 1), (1, 2), (2, 50), (50, 104))]
+    assert np.array_equal(np.concatenate(parts, axis=1), whole)
+    want, _ = oracle_run(blob_f32, feats[:, :12])
+    assert np.array_equal(whole[:, :12 * 160], want)
+    assert np.all(whole[:, :320] == 0) and np.any(whole[:, 320:480] != 0)
+    # determinism: run twice from reset
+    b.reset()
+    assert np.array_equal(b.synthesize(feats), whole)
+    b.close()
+
+
+def test_reset_subset_and_mixed_start(blob_f32, hip_lib):
+    """streams of one workgroup at different frame counts (one freshly reset): per-stream liveness."""
+    n, T = 4, 5
+    feats = feats_for([5000, 5001, 5002, 5003], T)
+    b = api.LPCNetBatch(n, blob_f32)
+    b.streams_per_workgroup = 4
+    first = b.synthesize(feats)
+    b.reset(1, 2)                                           # streams 1,2 start over; 0,3 continue
+    second = b.synthesize(feats)
+    om = orc.OracleModel(blob_f32)
+    for s in range(n):
+        st = om.new_state()
+        a = st.synthesize(feats[s])
+        assert np.array_equal(a, first[s])
+        if s in (1, 2):
+            st = om.new_state()
+        assert np.array_equal(st.synthesize(feats[s]), second[s])
+    b.close()
+
+
+def test_teacher_forcing_matches_reference_golden(blob_f32, golden, hip_lib):
+    f = feats_for([1000], 20)
+    b = api.LPCNetBatch(1, blob_f32)
+    forced = golden["forced_pcm_in"][None, :]
+    out = b.synthesize(f, preload_pcm=forced, preload=160)
+    assert np.array_equal(out, forced)                       # forced samples are not overwritten
+    st = b.get_state(0)
+    assert np.array_equal(np.array(st.gru_a, np.float32), golden["forced_gru_a"])
+    assert np.array_equal(np.array(st.gru_b, np.float32), golden["forced_gru_b"])
+    assert np.array_equal(np.array(st.last_sig, np.float32), golden["forced_last_sig"])
+    assert st.last_exc == int(golden["forced_last_exc"]) and np.array_equal(np.array(st.rng, np.uint32), golden["forced_rng"])
+    b.reset()
+    half_in = np.zeros((1, 20 * 160), np.int16)
+    for t in range(20):
+        half_in[0, t * 160:t * 160 + 80] = golden["forced_pcm_in"][t * 160:t * 160 + 80]
+    half = b.synthesize(f, preload_pcm=half_in, preload=80)
+    assert np.array_equal(half[0], golden["half_forced_pcm"])
+    b.close()
+
+
+def test_single_stream_c_api_like_lpcnet_demo(blob_f32, golden, hip_lib):
+    """lpcnet_create / lpcnet_load_model / lpcnet_synthesize per frame (src/lpcnet_demo.c:202-219),
+    POD state copy (PLC-style snapshot / rollback) and N < 160."""
+    T = 12
+    f = synth.make_features(1000, int(golden["n_frames"]))[:T]
+    st = api.LPCNetState(blob_f32)
+    pcm = np.concatenate([st.synthesize(f[t]) for t in range(T)])
+    assert np.array_equal(pcm, golden["pcm_gf_1000"][:T * 160])
+    # snapshot by value, run ahead, roll back, run again -> identical
+    L = hip_lib
+    size = L.lpcnet_get_size()
+    snap = C.string_at(st.p, size)
+    a = st.synthesize(f[3])
+    C.memmove(st.p, snap, size)
+    assert np.array_equal(st.synthesize(f[3]), a)
+    # N < 160: one frame-network step, N samples
+    om = orc.OracleModel(blob_f32)
+    o = om.new_state()
+    s2 = api.LPCNetState(blob_f32)
+    for t in range(6):
+        n = 160 if t % 2 == 0 else 57
+        want = np.zeros(n, np.int16)
+        o.L.orc_synthesize(o.p, np.ascontiguousarray(f[t, :20]), want, n, 0)
+        assert np.array_equal(s2.synthesize(f[t], n), want)
+
+
+def test_state_export_import_between_apis(blob_f32, hip_lib):
+    T = 8
+    feats = feats_for([6000, 6001], T)
+    b = api.LPCNetBatch(2, blob_f32)
+    b.synthesize(feats[:, :4])
+    st = api.LPCNetState(blob_f32)
+    assert hip_lib.lpcnet_batch_export_state(b.p, 1, st.p) == 0
+    tail_single = np.concatenate([st.synthesize(feats[1, t]) for t in range(4, T)])
+    tail_batch = b.synthesize(np.ascontiguousarray(feats[:, 4:]))
+    assert np.array_equal(tail_single, tail_batch[1])
+    b2 = api.LPCNetBatch(1, blob_f32)
+    st2 = api.LPCNetState(blob_f32)
+    assert hip_lib.lpcnet_batch_export_state(b.p, 0, st2.p) == 0 and hip_lib.lpcnet_batch_import_state(b2.p, 0, st2.p) == 0
+    more = feats_for([6002], 3)
+    assert np.array_equal(b2.synthesize(more)[0], np.concatenate([st2.synthesize(more[0, t]) for t in range(3)]))
+    b.close(); b2.close()
+
+
+def test_codec_path_matches_reference_golden(blob_f32, golden, hip_lib):
+    """lpcnet_decode: 8 bytes -> 640 samples (src/lpcnet.c:310-319) with seeded VQ codebooks."""
+    api.set_codebooks(*synth.make_codebooks(5))
+    dec = api.LPCNetDecState(blob_f32)
+    pcm = np.stack([dec.decode(p) for p in golden["packets"]])
+    assert np.array_equal(pcm, golden["packet_pcm_gf"])
+    b = api.LPCNetBatch(3, blob_f32)
+    pk = np.stack([golden["packets"]] * 3)
+    out = b.decode(pk)
+    for s in range(3):
+        assert np.array_equal(out[s], golden["packet_pcm_gf"].reshape(-1))
+    b.close()
+
+
+def test_device_pointer_api_with_torch(blob_f32, hip_lib):
+    """HBM-resident inputs/outputs on a caller stream (what bench.py times)."""
+    import torch
+    n, T = 8, 6
+    feats = feats_for(range(7000, 7000 + n), T)
+    want, _ = oracle_run(blob_f32, feats)
+    b = api.LPCNetBatch(n, blob_f32)
+    d_f = torch.from_numpy(feats).cuda()
+    d_p = torch.zeros((n, T * 160), dtype=torch.int16, device="cuda")
+    b.synthesize_device(d_f.data_ptr(), 36, d_p.data_ptr(), T, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_p.cpu().numpy(), want)
+    b.close()
+
+
+def test_lpc_kernel_random_cepstra(blob_f32, hip_lib, oracle_lib):
+    """wide random cepstra through the device LPC path (pow in double, 320-pt FFT, Levinson)."""
+    rng = np.random.default_rng(11)
+    n, T = 16, 40
+    feats = np.zeros((n, T, 36), np.float32)
+    feats[:, :, :18] = rng.standard_normal((n, T, 18)) * np.array([3.0] + [1.2] * 17)
+    feats[:, :, 18] = rng.uniform(-1.3, 3.0, (n, T))
+    b = api.LPCNetBatch(n, blob_f32)
+    _, _, glp = b.run_frames(feats)
+    out = np.zeros(16, np.float32)
+    for s in range(n):
+        for t in range(T - 2):
+            oracle_lib.orc_lpc_from_cepstrum(out, np.ascontiguousarray(feats[s, t, :18]))
+            assert np.array_equal(glp[s, t + 2], out), (s, t)       # two-frame delay line (src/lpcnet.c:110-112)
+        assert np.all(glp[s, :2] == 0)
+    b.close()
+
+
+def test_full_size_1024_streams_properties(blob_f32, golden, hip_lib):
+    """BASELINE config 2 size: 1024 concurrent streams.  Size-independent properties: streams fed the
+    same features are bit-identical to each other and to the reference golden; start-up frames are
+    silent; every stream is finite and non-degenerate."""
+    n, T = 1024, 12
+    base = feats_for([1000, 1001, 1002, 1003], T)
+    feats = np.ascontiguousarray(base[np.arange(n) % 4])
+    b = api.LPCNetBatch(n, blob_f32)
+    assert b.streams_per_workgroup == 4
+    pcm = b.synthesize(feats)
+    for k in range(4):
+        grp = pcm[k::4]
+        assert np.all(grp == grp[0])
+    for k, seed in enumerate((1000, 1001, 1002)):
+        assert np.array_equal(pcm[k], golden[f"pcm_gf_{seed}"][:T * 160])
+    want, _ = oracle_run(blob_f32, base)
+    assert np.array_equal(pcm[:4], want)
+    assert np.all(pcm[:, :320] == 0) and np.all(np.abs(pcm.astype(np.int32)).max(axis=1) > 0)
+    b.close()
+
+
+def test_int8_blob_is_refused_not_miscomputed(blob_i8, hip_lib):
+    with pytest.raises(api.LPCNetError):
+        api.LPCNetBatch(1, blob_i8)
