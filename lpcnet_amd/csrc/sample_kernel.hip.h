@@ -537,55 +537,73 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 // blocks, four u16 per 8-byte read.
                 const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
                 const int nq = (bend - bbeg) >> 2;                          // groups of 4 blocks
-                const float4 *wrow = (const float4 *)sm_bw + bbeg * 8 + ri;
+                // recurrent part first: an independent 16-term chain (src/nnet.c:356-361)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
+                // Software pipeline: loads for block b+2 are issued, products of block b+1 are formed
+                // (two packed multiplies) and the running sum takes the products of block b -- pinned with
+                // scheduling barriers so that every dependent add has independent work in its shadow.
+                // Reads past the end of a group fetch valid (unused) LDS data; the host pads the arrays.
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const unsigned char *wptr = smem + L::bw + (bbeg * 8 + ri) * 16;   // this lane's row, block 0 of its group
                 const unsigned char *hbase = smem + L::hA + s * 16;
                 const uint2 *offs = (const uint2 *)(sm_boff + bbeg);
-                // Software pipeline: loads for block b+2 are issued, products of block b+1 are formed and
-                // the running sum takes the products of block b -- pinned with scheduling barriers so
-                // that every dependent add has an independent multiply in its shadow.  Reads past the
-                // end of a group fetch valid (unused) LDS data; the host pads the arrays.
-                auto ldw = [&](int b) { return wrow[b * 8]; };
+                auto ldw = [&](int byte_off) { return *(const float4 *)(wptr + byte_off); };
                 auto ldh = [&](unsigned o) { return *(const float4 *)(hbase + o); };
                 uint2 o_cur = offs[0], o_nxt = offs[1];
                 float4 wa = ldw(0), ha = ldh(o_cur.x & 0xFFFFu);
-                float4 wb = ldw(1), hb = ldh(o_cur.x >> 16);
-                float p0 = wa.x * ha.x, p1 = wa.y * ha.y, p2 = wa.z * ha.z, p3 = wa.w * ha.w;
+                float4 wb = ldw(128), hb = ldh(o_cur.x >> 16);
+                f2 pl = (f2){wa.x, wa.y} * (f2){ha.x, ha.y}, ph = (f2){wa.z, wa.w} * (f2){ha.z, ha.w};
+#define LPCN_B_STEP(WN, HN, WLOAD, HLOAD)                                                               \
+                {                                                                                       \
+                    const float4 wl_ = WLOAD, hl_ = HLOAD;                                              \
+                    __builtin_amdgcn_sched_barrier(0);                                                  \
+                    const f2 ql_ = (f2){WN.x, WN.y} * (f2){HN.x, HN.y};                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                  \
+                    zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0);                                \
+                    zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);                                \
+                    const f2 qh_ = (f2){WN.z, WN.w} * (f2){HN.z, HN.w};                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                  \
+                    zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0);                                \
+                    zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);                                \
+                    pl = ql_; ph = qh_; WN = wl_; HN = hl_;                                             \
+                }
                 for (int q = 0; q < nq; ++q) {
-                    const float4 *wr = wrow + q * 32;
-                    // in flight: (wa,ha) = block 4q [products p], (wb,hb) = block 4q+1
-                    { const float4 w2 = wr[16], h2 = ldh(o_cur.y & 0xFFFFu);           // block 4q+2
+                    // in flight: (wa,ha) = block 4q with products (pl,ph); (wb,hb) = block 4q+1
+                    // each step: load block +2, multiply block +1, add block +0; WN/HN name the +1 block
+                    { const float4 w2 = ldw(256), h2 = ldh(o_cur.y & 0xFFFFu);
                       __builtin_amdgcn_sched_barrier(0);
-                      const float q0 = wb.x * hb.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
-                      const float q1 = wb.y * hb.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
-                      const float q2 = wb.z * hb.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
-                      const float q3 = wb.w * hb.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
-                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wa = w2; ha = h2; }
-                    { const float4 w3 = wr[24], h3 = ldh(o_cur.y >> 16);               // block 4q+3
+                      const f2 ql_ = (f2){wb.x, wb.y} * (f2){hb.x, hb.y}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
+                      const f2 qh_ = (f2){wb.z, wb.w} * (f2){hb.z, hb.w}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
+                      pl = ql_; ph = qh_; wa = w2; ha = h2; }
+                    { const float4 w3 = ldw(384), h3 = ldh(o_cur.y >> 16);
                       __builtin_amdgcn_sched_barrier(0);
-                      const float q0 = wa.x * ha.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
-                      const float q1 = wa.y * ha.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
-                      const float q2 = wa.z * ha.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
-                      const float q3 = wa.w * ha.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
-                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wb = w3; hb = h3; }
-                    { const float4 w4 = wr[32], h4 = ldh(o_nxt.x & 0xFFFFu);           // block 4q+4
+                      const f2 ql_ = (f2){wa.x, wa.y} * (f2){ha.x, ha.y}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
+                      const f2 qh_ = (f2){wa.z, wa.w} * (f2){ha.z, ha.w}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
+                      pl = ql_; ph = qh_; wb = w3; hb = h3; }
+                    { const float4 w4 = ldw(512), h4 = ldh(o_nxt.x & 0xFFFFu);
                       __builtin_amdgcn_sched_barrier(0);
-                      const float q0 = wb.x * hb.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
-                      const float q1 = wb.y * hb.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
-                      const float q2 = wb.z * hb.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
-                      const float q3 = wb.w * hb.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
-                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wa = w4; ha = h4; }
-                    { const float4 w5 = wr[40], h5 = ldh(o_nxt.x >> 16);               // block 4q+5
+                      const f2 ql_ = (f2){wb.x, wb.y} * (f2){hb.x, hb.y}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
+                      const f2 qh_ = (f2){wb.z, wb.w} * (f2){hb.z, hb.w}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
+                      pl = ql_; ph = qh_; wa = w4; ha = h4; }
+                    { const float4 w5 = ldw(640), h5 = ldh(o_nxt.x >> 16);
                       o_cur = o_nxt; o_nxt = offs[q + 2];
                       __builtin_amdgcn_sched_barrier(0);
-                      const float q0 = wa.x * ha.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p0; __builtin_amdgcn_sched_barrier(0);
-                      const float q1 = wa.y * ha.y; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p1; __builtin_amdgcn_sched_barrier(0);
-                      const float q2 = wa.z * ha.z; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p2; __builtin_amdgcn_sched_barrier(0);
-                      const float q3 = wa.w * ha.w; __builtin_amdgcn_sched_barrier(0); zrh = zrh + p3; __builtin_amdgcn_sched_barrier(0);
-                      p0 = q0; p1 = q1; p2 = q2; p3 = q3; wb = w5; hb = h5; }
+                      const f2 ql_ = (f2){wa.x, wa.y} * (f2){ha.x, ha.y}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
+                      const f2 qh_ = (f2){wa.z, wa.w} * (f2){ha.z, ha.w}; __builtin_amdgcn_sched_barrier(0);
+                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
+                      pl = ql_; ph = qh_; wb = w5; hb = h5; }
+                    wptr += 512;
                 }
+#undef LPCN_B_STEP
                 LPCN_PROF(8);      // GRU-B input mat-vec
-#pragma unroll
-                for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
                 // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
                 const float sg = lpcn_sigmoid(zrh + rec, sm_tansig);
                 const float r_gate = __shfl(sg, 16 + (lane & 15));
