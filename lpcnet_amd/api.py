@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblpcnet_hip.so")
+LIB_PATH = os.environ.get("LPCNET_HIP_LIB") or os.path.join(_HERE, "liblpcnet_hip.so")
 
 NB_FEATURES = 20
 NB_TOTAL_FEATURES = 36

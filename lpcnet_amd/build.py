@@ -31,12 +31,15 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, prof=False):
+    """prof=True builds liblpcnet_hip_prof.so with the in-kernel phase profiler compiled in
+    (tools only; select it with LPCNET_HIP_LIB=<path>)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     srcs += [os.path.join(HERE, "..", "include", f) for f in ("lpcnet.h", "lpcnet_batch.h")]
-    if not force and not _newer(LIB, srcs):
-        return LIB
-    objdir = os.path.join(HERE, "build")
+    lib = LIB.replace(".so", "_prof.so") if prof else LIB
+    if not force and not _newer(lib, srcs):
+        return lib
+    objdir = os.path.join(HERE, "build_prof" if prof else "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
 
@@ -46,16 +49,15 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
 
     o = os.path.join(objdir, "engine.o")
-    run([HIPCC] + HIP_FLAGS + ["-c", os.path.join(CSRC, "engine.hip"), "-o", o])
+    run([HIPCC] + HIP_FLAGS + (["-DLPCN_ENABLE_PROF=1"] if prof else []) + ["-c", os.path.join(CSRC, "engine.hip"), "-o", o])
     objs.append(o)
     for c in ("api.c", "model_pack.c"):
         o = os.path.join(objdir, c[:-2] + ".o")
         run(["gcc"] + C_FLAGS + ["-c", os.path.join(CSRC, c), "-o", o])
         objs.append(o)
-    run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lm"])
-    return LIB
+    run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread", "-lm"])
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, prof="--prof" in sys.argv))

@@ -64,6 +64,9 @@ struct LpcnSampleArgs {
     unsigned long long *prof;                       // optional: [8] shader-clock totals per phase, workgroup 0 wave 0
 };
 
+#ifndef LPCN_ENABLE_PROF
+#define LPCN_ENABLE_PROF 0
+#endif
 #define LPCN_DBG_STRIDE 420     // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,...
 
 namespace lpcn {
@@ -95,7 +98,8 @@ template <int S> struct Lds {
     static constexpr int cond   = inh + S * NA * 4;                 // [S][1152] frame conditioning (GRU-A)
     static constexpr int abias  = cond + S * RA * 4;                // [1152] recurrent bias
     static constexpr int adiag  = abias + RA * 4;                   // [1152] diagonal recurrent weights
-    static constexpr int hB     = adiag + RA * 4;                   // [S][16]
+    static constexpr int hT     = adiag + RA * 4;                   // [384][S] second copy of the GRU-A state, stream-interleaved
+    static constexpr int hB     = hT + NA * S * 4;                  // [S][16]
     static constexpr int idx    = hB + S * NB * 4;                  // [S][4] i32 (sig,pred,exc,live)
     static constexpr int thr    = idx + S * 16;                     // [S][8] f32
     static constexpr int mask   = thr + S * 32;                     // [S][8] u64
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     float *const sm_cond = (float *)(smem + L::cond);
     const float *const sm_abias = (const float *)(smem + L::abias);
     const float *const sm_adiag = (const float *)(smem + L::adiag);
+    float *const sm_hT = (float *)(smem + L::hT);
     float *const sm_hB = (float *)(smem + L::hB);
     int *const sm_idx = (int *)(smem + L::idx);
     float *const sm_thr = (float *)(smem + L::thr);
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         }
         const auto *ab1 = as_global(Ap->a_bias1), *adg = as_global(Ap->a_diag);
         for (int i = tid; i < RA; i += LPCN_WG_THREADS) {
-            ((float *)(smem + L::abias))[i] = ab1[i];
-            ((float *)(smem + L::adiag))[i] = adg[i];
+            ((float *)(smem + L::abias))[2 * i] = ab1[i];          // [row]{bias, diag}: one 8-byte read per row
+            ((float *)(smem + L::abias))[2 * i + 1] = adg[i];
         }
         const auto *br = as_global(Ap->b_rec), *bb = as_global(Ap->b_bias);
         for (int i = tid; i < NB * RB; i += LPCN_WG_THREADS) ((float *)(smem + L::brec))[i] = br[i];
@@ -222,7 +227,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         for (int i = tid; i < (nb_b + 2) * 32; i += LPCN_WG_THREADS) ((float *)(smem + L::bw))[i] = i < nb_b * 32 ? bw[i] : 0.f;
         for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
             const int s = i / NA, n = i % NA;
-            *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = states[stream_of(s)].gru_a[n];
+            const float hv0 = states[stream_of(s)].gru_a[n];
+            *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv0;
+            sm_hT[n * S + s] = hv0;
         }
         for (int i = tid; i < S * NB; i += LPCN_WG_THREADS) sm_hB[i] = states[stream_of(i / NB)].gru_b[i % NB];
         // leader-lane state (lane s of wave 0 leads stream s); kept in LDS between samples
@@ -268,10 +275,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         sm_idx[ls * 4 + 3] = live ? 1 : 0;
     };
 
+#if LPCN_ENABLE_PROF      // per-phase shader-clock accounting (profiling builds only: it costs VGPRs)
     unsigned long long *const prof = Ap->prof;
     unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     const bool profiling = prof != nullptr && blockIdx.x == 0 && (tid0 & 63) == 0;
 #define LPCN_PROF(slot) do { if (profiling) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[slot] += now_ - tprev; tprev = now_; } } while (0)
+#else
+#define LPCN_PROF(slot) do { } while (0)
+#endif
     // ====================================================================== frame loop ======
     for (int f = 0; f < n_frames; ++f) {
         // ---- frame-rate inputs -> LDS
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             const auto *ca = as_global(Ap->cond_a), *cb = as_global(Ap->cond_b), *lp = as_global(Ap->lpc);
             for (int i = tid; i < S * RA; i += LPCN_WG_THREADS) {
                 const int s = i / RA, r = i % RA;
-                sm_cond[i] = ca[((size_t)stream_of(s) * nf + f) * RA + r];
+                sm_cond[r * S + s] = ca[((size_t)stream_of(s) * nf + f) * RA + r];
             }
             if (tid < S * RB) sm_condb[tid] = cb[((size_t)stream_of(tid / RB) * nf + f) * RB + tid % RB];
             if (tid < S * LPCN_LPC_ORDER)
@@ -301,16 +312,20 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         __syncthreads();        // sm_lpc visible to the leaders
         if (tid0 < S) start_sample(tid0, live);
         __syncthreads();
-        int any_live = 0;
+        int live_mask = 0;                                   // bit s: stream s produces samples in this frame
 #pragma unroll
-        for (int s = 0; s < S; ++s) any_live |= sm_idx[s * 4 + 3];
+        for (int s = 0; s < S; ++s) live_mask |= (sm_idx[s * 4 + 3] ? 1 : 0) << s;
+        live_mask = __builtin_amdgcn_readfirstlane(live_mask);
+        const int any_live = live_mask;
         if (!any_live) {                                     // start-up frames: zeros, no state change
             for (int i = tid0; i < S * LPCN_FRAME_SIZE; i += LPCN_WG_THREADS) sm_pcm[i] = 0;
             __syncthreads();
         }
 
         // ================================================================== sample loop ====
+#if LPCN_ENABLE_PROF
         if (profiling) tprev = __builtin_amdgcn_s_memtime();
+#endif
         for (int smp = 0; any_live && smp < frame_len; ++smp) {
             // ---------------------------------------------------------------- P1: GRU-A ----
             // ---- embedding gather: one 16-byte row per table and stream holds the entries of this
@@ -348,15 +363,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 r = r < 0 ? 0 : r;
                 const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
                 const bool candidate = r >= 2 * NA;
-                const float bias = sm_abias[r], diag = sm_adiag[r];
+                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const float hprev = *(const float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4);
-                    const float b = bias + diag * hprev;
-                    const float g = ((sm_cond[s * RA + r] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
-                    if (candidate && live_row) sm_inh[s * NA + n] = g;
+                    const float b = bias + diag * sm_hT[n * S + s];
+                    const float g = ((sm_cond[r * S + s] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
+                    if (candidate && live_row) sm_inh[n * S + s] = g;
                     const float v = candidate ? b : b + g;
-                    if (to_acc) acc[s] = v; else if (live_row) sm_pre[s * RA + r] = v;
+                    if (to_acc) acc[s] = v; else if (live_row) sm_pre[r * S + s] = v;
                 }
             };
             auto row_swap = [&](const int k_done, const int k_next) {   // finished row out, next row in
@@ -365,18 +379,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 LPCN_REMAT_V(r2);
                 if (r >= 0) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[s * RA + r] = acc[s];
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc[s];
                 }
                 r2 = r2 < 0 ? 0 : r2;
 #pragma unroll
-                for (int s = 0; s < S; ++s) acc[s] = sm_pre[s * RA + r2];
+                for (int s = 0; s < S; ++s) acc[s] = sm_pre[r2 * S + s];
             };
             auto row_store = [&](const int k) {
                 int r = row[k];
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[s * RA + r] = acc[s];
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc[s];
                 }
             };
             // Waves whose first slot holds only candidate rows (the big ones) start it from
@@ -396,10 +410,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 int r = row[0];
                 r = r < 0 ? 0 : r;
                 const int n = r - 2 * NA;
-                const float bias = sm_abias[r], diag = sm_adiag[r];
+                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
                 for (int s = 0; s < S; ++s)
-                    acc[s] = bias + diag * *(const float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4);
+                    acc[s] = bias + diag * sm_hT[n * S + s];
             }
 #pragma unroll
             for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     const int n = r - 2 * NA;
 #pragma unroll
                     for (int s = 0; s < S; ++s)
-                        sm_inh[s * NA + n] = ((sm_cond[s * RA + r] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
+                        sm_inh[n * S + s] = ((sm_cond[r * S + s] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
                 }
             }
             LPCN_PROF(6);      // slots: begin + items + end
@@ -462,50 +476,50 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             int tid = tid0;
             LPCN_REMAT_V(tid);
             // ------------------------------------------------------------ P2: GRU-A gates --
-            // (a) update/reset gates: sigmoid over the 768*S pre-activations, spread over all lanes
+            // (a) update/reset gates: sigmoid over the 768 rows x S streams, rows spread over all lanes
             {
-                constexpr int NQ = (2 * NA * S + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
-                float v[NQ];
+                constexpr int NQ = (2 * NA + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
+                float v[NQ][S];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int e = tid + q * LPCN_WG_THREADS;
-                    const int s = e / (2 * NA), r = e - s * (2 * NA);
-                    v[q] = e < 2 * NA * S ? sm_pre[s * RA + r] : 0.f;
+                    const int r = tid + q * LPCN_WG_THREADS;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) v[q][s] = r < 2 * NA ? sm_pre[r * S + s] : 0.f;
                 }
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) v[q] = lpcn_sigmoid(v[q], sm_tansig);
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) v[q][s] = lpcn_sigmoid(v[q][s], sm_tansig);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int e = tid + q * LPCN_WG_THREADS;
-                    const int s = e / (2 * NA), r = e - s * (2 * NA);
-                    if (e < 2 * NA * S) sm_pre[s * RA + r] = v[q];
+                    const int r = tid + q * LPCN_WG_THREADS;
+                    if (r < 2 * NA) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) sm_pre[r * S + s] = v[q][s];
+                    }
                 }
             }
             __syncthreads();
-            // (b) candidate state and blend: 384*S (neuron, stream) pairs (src/nnet.c:443-447)
-            {
-                constexpr int NQ = (NA * S + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
-                float z[NQ], a[NQ], hold[NQ];
+            // (b) candidate state and blend, one lane per neuron, S streams each (src/nnet.c:443-447)
+            if (tid < NA) {
+                float z[S], a[S], hold[S];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int e = tid + q * LPCN_WG_THREADS;
-                    const int s = e / NA, i = e - s * NA;
-                    const bool ok = e < NA * S;
-                    const int ss = ok ? s : 0, ii = ok ? i : 0;
-                    z[q] = sm_pre[ss * RA + ii];
-                    const float r = sm_pre[ss * RA + NA + ii];
-                    a[q] = sm_pre[ss * RA + 2 * NA + ii] * r + sm_inh[ss * NA + ii];
-                    hold[q] = *(const float *)(smem + L::hA + L::ha_off(ii >> 2) + ss * 16 + (ii & 3) * 4);
+                for (int s = 0; s < S; ++s) {
+                    z[s] = sm_pre[tid * S + s];
+                    a[s] = sm_pre[(2 * NA + tid) * S + s] * sm_pre[(NA + tid) * S + s] + sm_inh[tid * S + s];
+                    hold[s] = sm_hT[tid * S + s];
                 }
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) a[q] = lpcn_tanh(a[q], sm_tansig);
+                for (int s = 0; s < S; ++s) a[s] = lpcn_tanh(a[s], sm_tansig);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int e = tid + q * LPCN_WG_THREADS;
-                    const int s = e / NA, i = e - s * NA;
-                    const float hnew = z[q] * hold[q] + (1.f - z[q]) * a[q];   // src/nnet.c:447
-                    if (e < NA * S && sm_idx[s * 4 + 3])
-                        *(float *)(smem + L::hA + L::ha_off(i >> 2) + s * 16 + (i & 3) * 4) = hnew;
+                for (int s = 0; s < S; ++s) {
+                    const float hnew = z[s] * hold[s] + (1.f - z[s]) * a[s];      // src/nnet.c:447
+                    a[s] = ((live_mask >> s) & 1) ? hnew : hold[s];
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    sm_hT[tid * S + s] = a[s];
+                    *(float *)(smem + L::hA + L::ha_off(tid >> 2) + s * 16 + (tid & 3) * 4) = a[s];
                 }
             }
             __syncthreads();                                                   // B2
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 if (lane < NB) {
                     const float hold = sm_hB[s * NB + lane];
                     const float hnew = sg * hold + (1.f - sg) * hc_i;
-                    if (sm_idx[s * 4 + 3]) sm_hB[s * NB + lane] = hnew;
+                    if ((live_mask >> s) & 1) sm_hB[s * NB + lane] = hnew;
                 }
             }
             __syncthreads();                                                   // B3
@@ -707,10 +721,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         __syncthreads();
     }
 
+#if LPCN_ENABLE_PROF
     if (profiling) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) prof[(tid0 >> 6) * 12 + i] += pt[i];
     }
+#endif
     // ------------------------------------------------------------------ write state back ----
     {
         const int tid = tid0;
