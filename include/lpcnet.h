@@ -66,7 +66,7 @@ LPCNET_EXPORT const char *lpcnet_hip_last_error(void);
 /* install the VQ codebooks used by lpcnet_decode (the reference compiles them in from
  * ceps_codebooks.c, a generated file that is not part of its tree): cb1..3 [1024][17], diff4 [4096][18] */
 LPCNET_EXPORT void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4);
-/* host-only blob validation (no GPU needed): 0 = loadable, 1 = valid int8 blob (unsupported), -1 = malformed.
+/* host-only blob validation (no GPU needed): 0 = loadable (float or int8 flavour), -1 = malformed.
  * info (may be NULL) receives {is_int8, GRU-A blocks, GRU-B blocks, items/lane, padded GRU-B blocks, selftest} */
 LPCNET_EXPORT int lpcnet_hip_check_model(const unsigned char *data, int len, int *info);
 /* release every device resource held for the single-stream API (optional, e.g. before exit) */

@@ -272,7 +272,7 @@ class LPCNetBatch:
         self._chk(self.L.lpcnet_batch_debug_trace(self.p, n_samples, None), "debug_trace")
 
     def debug_trace_fetch(self, n_samples):
-        out = np.zeros((n_samples, 420), np.float32)
+        out = np.zeros((n_samples, 1600), np.float32)
         self._chk(self.L.lpcnet_batch_debug_trace(self.p, n_samples, out.ctypes.data), "debug_trace")
         return out
 

@@ -410,16 +410,15 @@ int lpcnet_batch_profile(LPCNetBatch *b, unsigned long long *out) { NEED_MODEL(b
 
 /* Host-only model check (no GPU needed): parses the blob with the loader's rules, builds the device
  * packings and verifies them.  info[0..5] = {is_int8, blocks GRU-A, blocks GRU-B, items per lane,
- * padded GRU-B blocks, selftest code}.  Returns 0 if the blob is loadable by the engine, -1 if it is
- * malformed (lpcnet_load_model would fail), 1 if it is a valid int8 blob (not supported yet). */
+ * padded GRU-B blocks, selftest code}.  Returns 0 if the blob is loadable by the engine (float or
+ * int8 flavour, see info[0]), -1 if it is malformed (lpcnet_load_model would fail). */
 int lpcnet_hip_check_model(const unsigned char *data, int len, int *info)
 {
     lpcn_model_host m;
     if (lpcn_model_parse(&m, data, len) != 0) { set_err("malformed or incomplete DNNw weight blob"); return -1; }
     int st = lpcn_model_selftest(&m);
     if (info) { info[0] = m.is_int8; info[1] = m.nb_a; info[2] = m.nb_b; info[3] = m.nw; info[4] = m.nb_b_padded; info[5] = st; }
-    int int8 = m.is_int8;
     lpcn_model_release(&m);
     if (st) { set_err("internal error: device packing inconsistent with blob"); return -1; }
-    return int8 ? 1 : 0;
+    return 0;
 }

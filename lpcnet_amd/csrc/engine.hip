@@ -26,6 +26,7 @@ extern "C" const char *lpcn_last_error(void) { return g_err; }
 struct lpcn_engine {
     int device = 0;
     int nw = 0, nw_variant = 0, nb_b = 0;
+    bool is_int8 = false;
     float lpc_gamma = 1.f;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
@@ -70,18 +71,21 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
         return LPCN_E_NODEVICE;
     }
     if (device < 0 || device >= ndev) { snprintf(g_err, sizeof(g_err), "bad device %d (have %d)", device, ndev); return LPCN_E_ARG; }
-    if (m->is_int8) { snprintf(g_err, sizeof(g_err), "int8 (DOT_PROD) blobs are not supported by the fp32 engine"); return LPCN_E_MODEL; }
-    static const int variants[] = {24, 28, 30, 32, 36, 40};
+    // compiled item counts per lane: fp32 items are 4 VGPRs each, int8 items 1 VGPR
+    static const int variants_f32[] = {24, 28, 30, 32, 36, 40, 0};
+    static const int variants_i8[] = {32, 48, 64, 0};
     int nwv = 0;
-    for (int v : variants) if (m->nw <= v) { nwv = v; break; }
+    for (const int *v = m->is_int8 ? variants_i8 : variants_f32; *v; ++v) if (m->nw <= *v) { nwv = *v; break; }
     if (!nwv) {
-        snprintf(g_err, sizeof(g_err), "GRU-A too dense for the register-resident kernel (needs %d items/lane, max 40)", m->nw);
+        snprintf(g_err, sizeof(g_err), "GRU-A too dense for the register-resident kernel (needs %d items/lane, max %d)", m->nw,
+                 m->is_int8 ? 64 : 40);
         return LPCN_E_MODEL;
     }
     HIP_TRY(hipSetDevice(device));
     lpcn_engine *e = new lpcn_engine();
     e->device = device;
     e->nw = m->nw; e->nw_variant = nwv; e->nb_b = m->nb_b_padded; e->lpc_gamma = m->lpc_gamma;
+    e->is_int8 = m->is_int8 != 0;
     int rc = 0;
     auto fail = [&](int code) { lpcn_engine_destroy(e); return code; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail(LPCN_E_HIP);
@@ -89,14 +93,18 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     LpcnSampleArgs &a = e->sargs;
     // re-pad the item arrays from the model's nw to the compiled variant
     {
-        std::vector<float> w((size_t)LPCN_WAVES * nwv * 64 * 4, 0.f);
+        const size_t item_dw = m->is_int8 ? 1 : 4;            // dwords per (lane, item)
+        const uint32_t *src = m->is_int8 ? (const uint32_t *)m->pk_a_wq : (const uint32_t *)m->pk_a_w;
+        std::vector<uint32_t> w((size_t)LPCN_WAVES * nwv * 64 * item_dw, 0u);
         std::vector<uint8_t> b((size_t)LPCN_WAVES * nwv * 64, 0);
         for (int wv = 0; wv < LPCN_WAVES; ++wv)
             for (int j = 0; j < m->nw; ++j) {
-                memcpy(&w[((size_t)wv * nwv + j) * 64 * 4], &m->pk_a_w[((size_t)wv * m->nw + j) * 64 * 4], 64 * 4 * sizeof(float));
+                memcpy(&w[((size_t)wv * nwv + j) * 64 * item_dw], &src[((size_t)wv * m->nw + j) * 64 * item_dw], 64 * item_dw * 4);
                 memcpy(&b[((size_t)wv * nwv + j) * 64], &m->pk_a_blk[((size_t)wv * m->nw + j) * 64], 64);
             }
-        if ((rc = upload<float4>(e, &a.a_w, w.data(), w.size() / 4))) return fail(rc);
+        const uint32_t *d = nullptr;
+        if ((rc = upload<uint32_t>(e, &d, w.data(), w.size()))) return fail(rc);
+        a.a_w = (const float4 *)d;
         if ((rc = upload<uint8_t>(e, &a.a_blk, b.data(), b.size()))) return fail(rc);
     }
     int bound[LPCN_WAVES * 4], allh[LPCN_WAVES * 3];
@@ -114,10 +122,23 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     UP(float, emb_exc, m->pk_emb[2], (size_t)256 * LPCN_WG_THREADS * 4);
     UP(float, a_bias1, m->a_bias + LPCN_ROWS_A, LPCN_ROWS_A);
     UP(float, a_diag, m->a_diag, LPCN_ROWS_A);
-    UP(float, b_w, m->pk_b_w, (size_t)32 * m->nb_b_padded);
+    if (m->is_int8) {
+        const uint32_t *d = nullptr;
+        if ((rc = upload<uint32_t>(e, &d, m->pk_b_wq, (size_t)8 * m->nb_b_padded))) return fail(rc);
+        a.b_w = (const float *)d;
+        // recurrent matrix: blob layout [6 groups][4 column blocks][8 rows][4] -> [48 rows][4 blocks] dwords
+        uint32_t rq[LPCN_ROWS_B * 4];
+        const unsigned char *src = (const unsigned char *)m->b_rec;
+        for (int r = 0; r < LPCN_ROWS_B; ++r)
+            for (int jb = 0; jb < 4; ++jb) memcpy(&rq[r * 4 + jb], src + (((r >> 3) * 4 + jb) * 8 + (r & 7)) * 4, 4);
+        if ((rc = upload<uint32_t>(e, &d, rq, LPCN_ROWS_B * 4))) return fail(rc);
+        a.b_rec = (const float *)d;
+    } else {
+        UP(float, b_w, m->pk_b_w, (size_t)32 * m->nb_b_padded);
+        UP(float, b_rec, m->b_rec, LPCN_N_B * LPCN_ROWS_B);
+    }
     UP(int, b_start, m->pk_b_start, 7);
     UP(uint8_t, b_blk, m->pk_b_blk, m->nb_b_padded + 4);
-    UP(float, b_rec, m->b_rec, LPCN_N_B * LPCN_ROWS_B);
     UP(float, b_bias, m->b_bias, 2 * LPCN_ROWS_B);
     UP(float, fc_w, m->fc_w, 256 * 2 * LPCN_N_B);
     UP(float, fc_b, m->fc_b, 512);
@@ -127,6 +148,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     UP(float, tab_logit, lpcn_logit_tab, 256);
 #undef UP
     a.nb_b = m->nb_b_padded;
+    a.b_dense = m->b_dense;
 
     LpcnFrameModel &fm = e->fmodel;
 #define UPF(field, src, count) if ((rc = upload<float>(e, &fm.field, src, count))) return fail(rc)
@@ -277,13 +299,13 @@ extern "C" int lpcn_batch_dev_sync(lpcn_batch_dev *b)
 }
 
 // ------------------------------------------------------------------------------- launches -----
-template <int S, int NW>
+template <int S, int NW, bool I8>
 static int launch_sample_t(lpcn_batch_dev *b, hipStream_t st, bool dbg)
 {
-    const int lds = lpcn::Lds<S>::total(b->e->nb_b);
+    const int lds = lpcn::Lds<S>::total(b->e->nb_b, I8);
     const int grid = (b->n + S - 1) / S;
     (void)dbg;
-    auto k = lpcn::sample_kernel<S, NW>;
+    auto k = lpcn::sample_kernel<S, NW, I8>;
     HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(LPCN_WG_THREADS), lds, st, (const LpcnSampleArgs *)b->d_args);
     HIP_TRY(hipGetLastError());
@@ -293,13 +315,20 @@ static int launch_sample_t(lpcn_batch_dev *b, hipStream_t st, bool dbg)
 template <int S>
 static int launch_sample_s(lpcn_batch_dev *b, hipStream_t st, bool dbg)
 {
+    if (b->e->is_int8) {
+        switch (b->e->nw_variant) {
+        case 32: return launch_sample_t<S, 32, true>(b, st, dbg);
+        case 48: return launch_sample_t<S, 48, true>(b, st, dbg);
+        default: return launch_sample_t<S, 64, true>(b, st, dbg);
+        }
+    }
     switch (b->e->nw_variant) {
-    case 24: return launch_sample_t<S, 24>(b, st, dbg);
-    case 28: return launch_sample_t<S, 28>(b, st, dbg);
-    case 30: return launch_sample_t<S, 30>(b, st, dbg);
-    case 32: return launch_sample_t<S, 32>(b, st, dbg);
-    case 36: return launch_sample_t<S, 36>(b, st, dbg);
-    default: return launch_sample_t<S, 40>(b, st, dbg);
+    case 24: return launch_sample_t<S, 24, false>(b, st, dbg);
+    case 28: return launch_sample_t<S, 28, false>(b, st, dbg);
+    case 30: return launch_sample_t<S, 30, false>(b, st, dbg);
+    case 32: return launch_sample_t<S, 32, false>(b, st, dbg);
+    case 36: return launch_sample_t<S, 36, false>(b, st, dbg);
+    default: return launch_sample_t<S, 40, false>(b, st, dbg);
     }
 }
 

@@ -42,7 +42,8 @@ extern "C" {
 #define LPCN_MAX_SLOTS  3
 
 typedef struct lpcn_model_host {
-    int is_int8;                 /* blob flavour (int8 engine not in this round)               */
+    int is_int8;                 /* blob flavour: 0 = float qweights (DISABLE_DOT_PROD), 1 = int8 (DOT_PROD)  */
+    int b_dense;                 /* GRU-B input matrix lists every input block for every row group */
     int nb_a, nb_b;              /* 8x4 blocks in GRU-A recurrent / GRU-B input matrices       */
     int nw;                      /* items per lane needed by the register-resident packing     */
     int nb_b_padded;             /* GRU-B blocks after padding every row group to a multiple of 4 */
@@ -63,7 +64,9 @@ typedef struct lpcn_model_host {
     const float *b_rec;                             /* [16][48]                                */
 
     /* device-oriented packings built by lpcn_model_pack() (malloc'ed, owned by the model)     */
-    float   *pk_a_w;      /* [8 waves][nw][64 lanes][4]     row weights per item               */
+    float   *pk_a_w;      /* [8 waves][nw][64 lanes][4]     row weights per item (float blobs)  */
+    int32_t *pk_a_wq;     /* [8 waves][nw][64 lanes]        4 int8 row weights per item (int8)  */
+    int32_t *pk_b_wq;     /* [blk/4][row-in-group 8][blk%4] 4 int8 per row and block (int8)     */
     uint8_t *pk_a_blk;    /* [8][nw][64]                    input block index p = pos/4        */
     int32_t *pk_a_row;    /* [8][3 slots][64]               GRU-A row (0..1151) or -1          */
     int32_t  pk_a_bound[LPCN_WAVES][LPCN_MAX_SLOTS + 1];    /* item index where each slot starts */

@@ -141,10 +141,11 @@ static int pack_gru_a(lpcn_model_host *m)
     for (int w = 0; w < LPCN_WAVES; w++) if (load[w] > nw) nw = load[w];
     m->nw = nw;
 
-    m->pk_a_w   = (float *)calloc((size_t)LPCN_WAVES * nw * 64 * 4, sizeof(float));
+    if (m->is_int8) m->pk_a_wq = (int32_t *)calloc((size_t)LPCN_WAVES * nw * 64, sizeof(int32_t));
+    else            m->pk_a_w  = (float *)calloc((size_t)LPCN_WAVES * nw * 64 * 4, sizeof(float));
     m->pk_a_blk = (uint8_t *)calloc((size_t)LPCN_WAVES * nw * 64, 1);
     m->pk_a_row = (int32_t *)malloc(sizeof(int32_t) * LPCN_WAVES * LPCN_MAX_SLOTS * 64);
-    if (!m->pk_a_w || !m->pk_a_blk || !m->pk_a_row) return -1;
+    if ((!m->pk_a_w && !m->pk_a_wq) || !m->pk_a_blk || !m->pk_a_row) return -1;
     for (int i = 0; i < LPCN_WAVES * LPCN_MAX_SLOTS * 64; i++) m->pk_a_row[i] = -1;
 
     int fill[LPCN_WAVES] = {0}, cur[LPCN_WAVES] = {0};
@@ -160,9 +161,14 @@ static int pack_gru_a(lpcn_model_host *m)
                 int lane = 8 * q + r;
                 m->pk_a_row[(w * LPCN_MAX_SLOTS + k) * 64 + lane] = rg->group * 8 + r;
                 for (int j = 0; j < rg->count; j++) {
-                    const float *blkw = m->a_w + (size_t)(rg->first_block + j) * 32;   /* [in 4][out 8] */
                     size_t item = ((size_t)w * nw + (j0 + j)) * 64 + lane;
-                    for (int c = 0; c < 4; c++) m->pk_a_w[item * 4 + c] = blkw[c * 8 + r];
+                    if (m->is_int8) {      /* int8 block = [out 8][in 4] (dump_lpcnet.py:106): the row's 4 bytes are one dword */
+                        const signed char *blkq = (const signed char *)m->a_w + (size_t)(rg->first_block + j) * 32;
+                        memcpy(&m->pk_a_wq[item], blkq + r * 4, 4);
+                    } else {               /* float block = [in 4][out 8] (dump_lpcnet.py:107) */
+                        const float *blkw = m->a_w + (size_t)(rg->first_block + j) * 32;
+                        for (int c = 0; c < 4; c++) m->pk_a_w[item * 4 + c] = blkw[c * 8 + r];
+                    }
                     m->pk_a_blk[item] = (uint8_t)(rg->pos[j] >> 2);
                 }
             }
@@ -199,27 +205,37 @@ static int pack_gru_a(lpcn_model_host *m)
 static int pack_gru_b(lpcn_model_host *m)
 {
     enum { NG = LPCN_ROWS_B / 8 };
-    const size_t cap = (size_t)m->nb_b + 3 * NG + 4;     /* every group padded to a multiple of 4 blocks */
-    m->pk_b_w = (float *)calloc(32 * cap, sizeof(float));
+    const size_t cap = (size_t)m->nb_b + 3 * NG + 8;     /* every group padded to a multiple of 4 blocks */
+    if (m->is_int8) m->pk_b_wq = (int32_t *)calloc(8 * cap, sizeof(int32_t));
+    else            m->pk_b_w = (float *)calloc(32 * cap, sizeof(float));
     m->pk_b_blk = (uint8_t *)calloc(cap, 1);
     m->pk_b_start = (int32_t *)malloc(sizeof(int32_t) * (NG + 1));
-    if (!m->pk_b_w || !m->pk_b_blk || !m->pk_b_start) return -1;
+    if ((!m->pk_b_w && !m->pk_b_wq) || !m->pk_b_blk || !m->pk_b_start) return -1;
     const int *idx = m->b_idx;
-    int src_blk = 0, dst = 0;
+    int src_blk = 0, dst = 0, dense = 1;
     for (int g = 0; g < NG; g++) {
         int cnt = *idx++;
         m->pk_b_start[g] = dst;
+        if (cnt != LPCN_N_A / 4) dense = 0;
         for (int j = 0; j < cnt; j++, src_blk++, dst++) {
-            const float *src = m->b_w + (size_t)src_blk * 32;
-            float *out = m->pk_b_w + (size_t)dst * 32;
-            for (int r = 0; r < 8; r++)
-                for (int c = 0; c < 4; c++) out[r * 4 + c] = src[c * 8 + r];
+            if (m->is_int8) {          /* [out 8][in 4] int8: one dword per row; four blocks of a row side by side */
+                const signed char *src = (const signed char *)m->b_w + (size_t)src_blk * 32;
+                for (int r = 0; r < 8; r++)
+                    memcpy(m->pk_b_wq + ((size_t)(dst >> 2) * 8 + r) * 4 + (dst & 3), src + r * 4, 4);
+            } else {
+                const float *src = m->b_w + (size_t)src_blk * 32;
+                float *out = m->pk_b_w + (size_t)dst * 32;
+                for (int r = 0; r < 8; r++)
+                    for (int c = 0; c < 4; c++) out[r * 4 + c] = src[c * 8 + r];
+            }
+            if ((*idx >> 2) != j) dense = 0;
             m->pk_b_blk[dst] = (uint8_t)(*idx++ >> 2);
         }
         while (dst & 3) dst++;                           /* zero-weight padding blocks (input block 0) */
     }
     m->pk_b_start[NG] = dst;
     m->nb_b_padded = dst;
+    m->b_dense = dense;                                  /* every row group lists all 96 input blocks in order */
     return 0;
 }
 
@@ -275,14 +291,14 @@ int lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len)
     if (!(m->b_w = (const float *)blob_need(rec, n, "gru_b_weights", q * 32 * (size_t)m->nb_b))) return -1;
     if (!(m->b_rec = (const float *)blob_need(rec, n, "gru_b_recurrent_weights", q * LPCN_ROWS_B * LPCN_N_B))) return -1;
 
-    if (m->is_int8) return 0;                       /* valid blob; packings are float-only       */
     if (pack_gru_a(m) || pack_gru_b(m)) { lpcn_model_release(m); return -1; }
     return 0;
 }
 
 void lpcn_model_release(lpcn_model_host *m)
 {
-    free(m->pk_a_w); free(m->pk_a_blk); free(m->pk_a_row);
+    free(m->pk_a_w); free(m->pk_a_wq); free(m->pk_b_wq); free(m->pk_a_blk); free(m->pk_a_row);
+    m->pk_a_wq = NULL; m->pk_b_wq = NULL;
     free(m->pk_b_w); free(m->pk_b_start); free(m->pk_b_blk);
     for (int i = 0; i < 3; i++) { free(m->pk_emb[i]); m->pk_emb[i] = NULL; }
     m->pk_a_w = NULL; m->pk_a_blk = NULL; m->pk_a_row = NULL;
@@ -292,9 +308,67 @@ void lpcn_model_release(lpcn_model_host *m)
 /* Consistency check of the device packings against the blob they were built from: re-expands both
  * to dense matrices and compares them bit for bit.  Used by the CPU test-suite and by
  * lpcnet_hip_check_model(); returns 0 when consistent, a positive code naming the first mismatch. */
+static int selftest_i8(const lpcn_model_host *m)
+{
+    int rc = 0;
+    signed char *dense = (signed char *)calloc((size_t)LPCN_N_A * LPCN_ROWS_A, 1);
+    signed char *packed = (signed char *)calloc((size_t)LPCN_N_A * LPCN_ROWS_A, 1);
+    if (!dense || !packed) { rc = 100; goto done; }
+    {
+        const int *idx = m->a_idx;
+        const signed char *w = (const signed char *)m->a_w;
+        for (int g = 0; g < LPCN_ROWS_A / 8; g++) {
+            int cnt = *idx++;
+            for (int j = 0; j < cnt; j++, w += 32) {
+                int pos = *idx++;
+                for (int r = 0; r < 8; r++)
+                    for (int c = 0; c < 4; c++) dense[(size_t)(pos + c) * LPCN_ROWS_A + g * 8 + r] = w[r * 4 + c];
+            }
+        }
+    }
+    for (int wv = 0; wv < LPCN_WAVES; wv++)
+        for (int k = 0; k < LPCN_MAX_SLOTS; k++)
+            for (int lane = 0; lane < 64; lane++) {
+                int row = m->pk_a_row[(wv * LPCN_MAX_SLOTS + k) * 64 + lane];
+                if (row < 0) continue;
+                for (int j = m->pk_a_bound[wv][k]; j < m->pk_a_bound[wv][k + 1]; j++) {
+                    size_t item = ((size_t)wv * m->nw + j) * 64 + lane;
+                    signed char q[4];
+                    memcpy(q, &m->pk_a_wq[item], 4);
+                    for (int c = 0; c < 4; c++) if (q[c]) packed[(size_t)(m->pk_a_blk[item] * 4 + c) * LPCN_ROWS_A + row] = q[c];
+                }
+            }
+    if (memcmp(dense, packed, (size_t)LPCN_N_A * LPCN_ROWS_A)) { rc = 5; goto done; }
+    memset(dense, 0, (size_t)LPCN_N_A * LPCN_ROWS_B);
+    memset(packed, 0, (size_t)LPCN_N_A * LPCN_ROWS_B);
+    {
+        const int *idx = m->b_idx;
+        const signed char *w = (const signed char *)m->b_w;
+        for (int g = 0; g < LPCN_ROWS_B / 8; g++) {
+            int cnt = *idx++;
+            for (int j = 0; j < cnt; j++, w += 32) {
+                int pos = *idx++, b = m->pk_b_start[g] + j;
+                if (m->pk_b_blk[b] != pos / 4) { rc = 8; goto done; }
+                for (int r = 0; r < 8; r++) {
+                    signed char q[4];
+                    memcpy(q, &m->pk_b_wq[((size_t)(b >> 2) * 8 + r) * 4 + (b & 3)], 4);
+                    for (int c = 0; c < 4; c++) {
+                        dense[(size_t)(pos + c) * LPCN_ROWS_B + g * 8 + r] = w[r * 4 + c];
+                        packed[(size_t)(pos + c) * LPCN_ROWS_B + g * 8 + r] = q[c];
+                    }
+                }
+            }
+        }
+    }
+    if (memcmp(dense, packed, (size_t)LPCN_N_A * LPCN_ROWS_B)) rc = 10;
+done:
+    free(dense); free(packed);
+    return rc;
+}
+
 int lpcn_model_selftest(const lpcn_model_host *m)
 {
-    if (m->is_int8) return 0;
+    if (m->is_int8) return selftest_i8(m);
     int rc = 0;
     float *dense = (float *)calloc((size_t)LPCN_N_A * LPCN_ROWS_A, sizeof(float));
     float *packed = (float *)calloc((size_t)LPCN_N_A * LPCN_ROWS_A, sizeof(float));

@@ -29,27 +29,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "lpcnet_engine.h"
 #include "lpcnet_math.h"
 
 struct LpcnSampleArgs {
     // model (device pointers)
     const float *emb_sig, *emb_pred, *emb_exc;      // [256][512 threads][4]: lane-ordered embedding tables
-    const float4 *a_w;                              // [8][NW][64]
+    const float4 *a_w;                              // [8][NW][64] float4 (fp32 blobs) or [8][NW][64] dwords of 4 int8 (int8 blobs)
     const uint8_t *a_blk;                           // [8][NW][64]
     const int *a_row;                               // [8][3][64]
     const int *a_bound;                             // [8][4]
     const int *a_allh;                              // [8][3]
     const float *a_bias1;                           // [1152] recurrent bias row
     const float *a_diag;                            // [1152]
-    const float *b_w;                               // [nb_b][8][4]
+    const float *b_w;                               // [nb_b][8][4] fp32, or [nb_b/4][8][4 blocks] dwords of 4 int8
     const int *b_start;                             // [7]
     const uint8_t *b_blk;                           // [nb_b]
-    const float *b_rec;                             // [16][48]
+    const float *b_rec;                             // [16][48] fp32, or [48 rows][4] dwords of 4 int8
     const float *b_bias;                            // [2][48]
     const float *fc_w, *fc_b, *fc_f;                // [256][2][16], [2][256], [2][256]
     const float *tab_tansig, *tab_ulaw2lin, *tab_logit;
     int nb_b;
+    int b_dense;                                    // GRU-B lists all 96 input blocks for every row group, in order
     // work
     int n_streams, n_frames, preload, fc_advance;
     int frame_len;                                  // samples synthesised per frame (1..160)
@@ -67,7 +69,7 @@ struct LpcnSampleArgs {
 #ifndef LPCN_ENABLE_PROF
 #define LPCN_ENABLE_PROF 0
 #endif
-#define LPCN_DBG_STRIDE 420     // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,...
+#define LPCN_DBG_STRIDE 1600    // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,pred; [448..1600) GRU-A pre-activations
 
 namespace lpcn {
 
@@ -96,8 +98,8 @@ template <int S> struct Lds {
     static constexpr int pre    = hA + hA_sz;                       // [S][1152] f32 pre-activations
     static constexpr int inh    = pre + S * RA * 4;                 // [S][384]  input part of candidate rows
     static constexpr int cond   = inh + S * NA * 4;                 // [S][1152] frame conditioning (GRU-A)
-    static constexpr int abias  = cond + S * RA * 4;                // [1152] recurrent bias
-    static constexpr int adiag  = abias + RA * 4;                   // [1152] diagonal recurrent weights
+    static constexpr int abias  = cond + S * RA * 4;                // [1152]{bias, diag}: recurrent bias and diagonal weight per row
+    static constexpr int adiag  = abias + RA * 4;                   // (second half of the interleaved {bias, diag} table)
     static constexpr int hT     = adiag + RA * 4;                   // [384][S] second copy of the GRU-A state, stream-interleaved
     static constexpr int hB     = hT + NA * S * 4;                  // [S][16]
     static constexpr int idx    = hB + S * NB * 4;                  // [S][4] i32 (sig,pred,exc,live)
@@ -117,7 +119,11 @@ template <int S> struct Lds {
     static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
     static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
-    static constexpr int total(int nb_b) { return bw + (nb_b + 2) * 128; }   // +2 blocks: the GRU-B pipeline reads ahead
+    static constexpr int total(int nb_b, bool i8) { return bw + (nb_b + 8) * (i8 ? 32 : 128); }   // pad: the GRU-B pipeline reads ahead
+    // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
+    static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
+    static constexpr int xqT    = hA + 384 * S;                     // [S][96] dwords: the same, stream-major (GRU-B input)
+    static constexpr int hBq    = hA + 768 * S;                     // [S][4] dwords: quantised GRU-B state
     __host__ __device__ static constexpr int ha_off(int p) { return p * HA_STRIDE + (p >> 2) * 16; }
 };
 
@@ -127,10 +133,67 @@ template <int SEL> __device__ __forceinline__ float quad_bcast(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SEL * 0x55, 0xf, 0xf, true));
 }
 
-template <int S, int NW>
+// int8 (DOT_PROD) arithmetic of the reference's generic-C build, src/vec.h:274-339:
+//   x_q = (signed char)(int)floor(.5 + 127*x)   (float product, double sum)
+//   out = out*(128*127);  out += (w0*x0 + w1*x1 + w2*x2 + w3*x3) per block (exact integer);  out *= 1/128/127
+constexpr float QS = 128.f * 127.f, QS1 = 1.f / 128.f / 127.f;
+__device__ __forceinline__ int quant_s8(float x)
+{
+    const float t = 127.f * x;
+    return (int)floor(.5 + (double)t) & 0xFF;
+}
+// Integer dot products converted to float.  v_dot4_i32_i8 with a literal-zero accumulator saves the
+// v_mov the compiler's v_dot4c selection needs, but the hazard recogniser cannot see inside inline
+// asm: gfx90a+ requires 3 wait states between a DOT write and a different VALU op reading the
+// result (and 4 before a different VALU op overwrites it), so every block below carries its own
+// spacing -- the dots of the other streams, or s_nop.
+__device__ __forceinline__ void dot4_cvt_x4(float (&f)[4], int w0, int w1, int w2, int w3, int x0, int x1, int x2, int x3)
+{
+    int t0, t1, t2, t3;
+    asm("v_dot4_i32_i8 %4, %8, %12, 0\n\t"
+        "v_dot4_i32_i8 %5, %9, %13, 0\n\t"
+        "v_dot4_i32_i8 %6, %10, %14, 0\n\t"
+        "v_dot4_i32_i8 %7, %11, %15, 0\n\t"
+        "v_cvt_f32_i32 %0, %4\n\t"
+        "v_cvt_f32_i32 %1, %5\n\t"
+        "v_cvt_f32_i32 %2, %6\n\t"
+        "v_cvt_f32_i32 %3, %7"
+        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+}
+__device__ __forceinline__ void dot4_cvt_x2(float (&f)[2], int w0, int w1, int x0, int x1)
+{
+    int t0, t1;
+    asm("v_dot4_i32_i8 %2, %4, %6, 0\n\t"
+        "v_dot4_i32_i8 %3, %5, %7, 0\n\t"
+        "s_nop 1\n\t"
+        "v_cvt_f32_i32 %0, %2\n\t"
+        "v_cvt_f32_i32 %1, %3"
+        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(t0), "=&v"(t1)
+        : "v"(w0), "v"(w1), "v"(x0), "v"(x1));
+}
+__device__ __forceinline__ float dot4_cvt(int w, int x)
+{
+    float f;
+    int t0;
+    asm("v_dot4_i32_i8 %1, %2, %3, 0\n\t"
+        "s_nop 2\n\t"
+        "v_cvt_f32_i32 %0, %1"
+        : "=&v"(f), "=&v"(t0)
+        : "v"(w), "v"(x));
+    return f;
+}
+template <int S> struct XVec;
+template <> struct XVec<1> { typedef int type; };
+template <> struct XVec<2> { typedef int type __attribute__((ext_vector_type(2))); };
+template <> struct XVec<4> { typedef int type __attribute__((ext_vector_type(4))); };
+
+template <int S, int NW, bool I8>
 __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
 {
     using L = Lds<S>;
+    using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
+    using HT = typename std::conditional<I8, typename XVec<S>::type, float4>::type;   // one fetched state block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const sm_pre = (float *)(smem + L::pre);
     float *const sm_inh = (float *)(smem + L::inh);
@@ -170,25 +233,32 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     const auto *const emb_exc = as_global(Ap->emb_exc);
 
     // ------------------------------------------------------------------ resident weights ----
-    float4 w[NW];
+    WT w[NW];
     uint32_t offp[(NW + 1) / 2];
     int row[3];
     {
         const int lane = tid0 & 63, wave = tid0 >> 6;
         const size_t base = (size_t)wave * NW * 64 + lane;
         const int lane_sel = (S >= 4 ? (lane & 3) : (S == 2 ? (lane & 1) : 0)) * 16;
-        const auto *aw = (const LPCN_GLOBAL float *)as_global(Ap->a_w);
         const auto *ab = as_global(Ap->a_blk);
+        if constexpr (I8) {
+            const auto *aq = (const LPCN_GLOBAL int *)as_global(Ap->a_w);
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const auto *v = aw + (base + (size_t)j * 64) * 4;
-            w[j] = make_float4(v[0], v[1], v[2], v[3]);
+            for (int j = 0; j < NW; ++j) w[j] = aq[base + (size_t)j * 64];
+        } else {
+            const auto *aw = (const LPCN_GLOBAL float *)as_global(Ap->a_w);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const auto *v = aw + (base + (size_t)j * 64) * 4;
+                w[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NW; j += 2) {
             const int p0 = ab[base + (size_t)j * 64];
             const int p1 = (j + 1 < NW) ? ab[base + (size_t)(j + 1) * 64] : 0;
-            offp[j >> 1] = (uint32_t)(L::ha_off(p0) + lane_sel) | ((uint32_t)(L::ha_off(p1) + lane_sel) << 16);
+            if constexpr (I8) offp[j >> 1] = (uint32_t)(p0 * 4 * S) | ((uint32_t)(p1 * 4 * S) << 16);
+            else offp[j >> 1] = (uint32_t)(L::ha_off(p0) + lane_sel) | ((uint32_t)(L::ha_off(p1) + lane_sel) << 16);
         }
         const auto *ar = as_global(Ap->a_row);
 #pragma unroll
@@ -197,6 +267,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     int b1 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 1]);
     int b2 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 2]);
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
+    const bool b_dense = Ap->b_dense != 0;
 
     // ------------------------------------------------------------------ LDS residents -------
     {
@@ -214,24 +285,35 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             ((float *)(smem + L::abias))[2 * i + 1] = adg[i];
         }
         const auto *br = as_global(Ap->b_rec), *bb = as_global(Ap->b_bias);
-        for (int i = tid; i < NB * RB; i += LPCN_WG_THREADS) ((float *)(smem + L::brec))[i] = br[i];
+        for (int i = tid; i < (I8 ? RB * 4 : NB * RB); i += LPCN_WG_THREADS) ((uint32_t *)(smem + L::brec))[i] = ((const LPCN_GLOBAL uint32_t *)br)[i];   // bit copy (dwords of 4 int8 for I8)
         for (int i = tid; i < 2 * RB; i += LPCN_WG_THREADS) ((float *)(smem + L::bbias))[i] = bb[i];
         if (tid < 7) ((int *)(smem + L::bstart))[tid] = as_global(Ap->b_start)[tid];
         const auto *bk = as_global(Ap->b_blk);
         for (int i = tid; i < 608; i += LPCN_WG_THREADS) {
             const int pblk = i < nb_b ? bk[i] : 0;
             smem[L::bblk + i] = (unsigned char)pblk;
-            ((unsigned short *)(smem + L::boff))[i] = (unsigned short)L::ha_off(pblk);
+            ((unsigned short *)(smem + L::boff))[i] = (unsigned short)(I8 ? pblk * 4 : L::ha_off(pblk));
         }
         const auto *bw = as_global(Ap->b_w);
-        for (int i = tid; i < (nb_b + 2) * 32; i += LPCN_WG_THREADS) ((float *)(smem + L::bw))[i] = i < nb_b * 32 ? bw[i] : 0.f;
+        constexpr int BW_DW = I8 ? 8 : 32;                  // dwords per GRU-B block
+        for (int i = tid; i < (nb_b + 8) * BW_DW; i += LPCN_WG_THREADS) ((uint32_t *)(smem + L::bw))[i] = i < nb_b * BW_DW ? ((const LPCN_GLOBAL uint32_t *)bw)[i] : 0u;
         for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
             const int s = i / NA, n = i % NA;
             const float hv0 = states[stream_of(s)].gru_a[n];
-            *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv0;
             sm_hT[n * S + s] = hv0;
+            if constexpr (I8) {
+                const unsigned char q = (unsigned char)quant_s8(hv0);
+                smem[L::xq + ((n >> 2) * S + s) * 4 + (n & 3)] = q;
+                smem[L::xqT + (s * 96 + (n >> 2)) * 4 + (n & 3)] = q;
+            } else {
+                *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv0;
+            }
         }
-        for (int i = tid; i < S * NB; i += LPCN_WG_THREADS) sm_hB[i] = states[stream_of(i / NB)].gru_b[i % NB];
+        for (int i = tid; i < S * NB; i += LPCN_WG_THREADS) {
+            const float hv0 = states[stream_of(i / NB)].gru_b[i % NB];
+            sm_hB[i] = hv0;
+            if constexpr (I8) smem[L::hBq + i] = (unsigned char)quant_s8(hv0);
+        }
         // leader-lane state (lane s of wave 0 leads stream s); kept in LDS between samples
         if (tid < S) {
             const auto *st = &states[stream_of(tid)];
@@ -345,12 +427,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             float acc[S];
             // state blocks are fetched PF items ahead of their use
             constexpr int PF = 2;
-            float4 hq[PF + 1];
+            HT hq[PF + 1];
             auto fetch_h = [&](const int j) {
                 uint32_t pk = offp[j >> 1];
                 LPCN_REMAT_V(pk);                            // keep the unpack inside the sample loop
                 const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
-                hq[j % (PF + 1)] = *(const float4 *)(smem + L::hA + off);
+                hq[j % (PF + 1)] = *(const HT *)(smem + L::hA + off);
             };
             // start value of row slot k: bias + diag*h (+ gathered input for the update/reset rows),
             // gather sum in the reference's order ((cond + sig) + pred) + exc (src/nnet.c:431-440,
@@ -369,7 +451,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     const float b = bias + diag * sm_hT[n * S + s];
                     const float g = ((sm_cond[r * S + s] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
                     if (candidate && live_row) sm_inh[n * S + s] = g;
-                    const float v = candidate ? b : b + g;
+                    float v = candidate ? b : b + g;
+                    if constexpr (I8) v = v * QS;
                     if (to_acc) acc[s] = v; else if (live_row) sm_pre[r * S + s] = v;
                 }
             };
@@ -379,7 +462,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 LPCN_REMAT_V(r2);
                 if (r >= 0) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc[s];
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
                 }
                 r2 = r2 < 0 ? 0 : r2;
 #pragma unroll
@@ -390,7 +473,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc[s];
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
                 }
             };
             // Waves whose first slot holds only candidate rows (the big ones) start it from
@@ -412,8 +495,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 const int n = r - 2 * NA;
                 const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
-                for (int s = 0; s < S; ++s)
+                for (int s = 0; s < S; ++s) {
                     acc[s] = bias + diag * sm_hT[n * S + s];
+                    if constexpr (I8) acc[s] = acc[s] * QS;
+                }
             }
 #pragma unroll
             for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
@@ -430,6 +515,22 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 if (j + PF < NW) fetch_h(j + PF);
                 // one item = (this lane's row) x (one 4-wide input block) for all S streams; per output
                 // the products are added in block order, columns 0..3 (src/vec.h:355-401)
+                if constexpr (I8) {
+                    // one dot4 = the row's block product for one stream, exact in int32 (src/vec.h:329-334)
+                    const HT xv = hq[j % (PF + 1)];
+                    if constexpr (S == 4) {
+                        float d[4];
+                        dot4_cvt_x4(d, w[j], w[j], w[j], w[j], xv[0], xv[1], xv[2], xv[3]);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc[s] = acc[s] + d[s];
+                    } else if constexpr (S == 2) {
+                        float d[2];
+                        dot4_cvt_x2(d, w[j], w[j], xv[0], xv[1]);
+                        acc[0] = acc[0] + d[0]; acc[1] = acc[1] + d[1];
+                    } else {
+                        acc[0] = acc[0] + dot4_cvt(w[j], xv);
+                    }
+                } else {
                 const float4 hv = hq[j % (PF + 1)];
                 const float hk[4] = {hv.x, hv.y, hv.z, hv.w};
                 const float wk[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
@@ -445,6 +546,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                         const float t2 = wk[c] * quad_bcast<2>(hk[c]), t3 = wk[c] * quad_bcast<3>(hk[c]);
                         acc[0] = acc[0] + t0; acc[1] = acc[1] + t1; acc[2] = acc[2] + t2; acc[3] = acc[3] + t3;
                     }
+                }
                 }
             }
             // close whichever slot is still open; slots that start exactly at NW have no items
@@ -472,6 +574,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             LPCN_PROF(6);      // slots: begin + items + end
             __syncthreads();                                                   // B1
             LPCN_PROF(0);
+            if (Ap->dbg && blockIdx.x == 0) {                                  // tests: recurrent pre-activations of stream 0
+                float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 448;
+                for (int i = tid0; i < RA; i += LPCN_WG_THREADS) d[i] = sm_pre[i * S];
+            }
 
             int tid = tid0;
             LPCN_REMAT_V(tid);
@@ -519,7 +625,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     sm_hT[tid * S + s] = a[s];
-                    *(float *)(smem + L::hA + L::ha_off(tid >> 2) + s * 16 + (tid & 3) * 4) = a[s];
+                    if constexpr (I8) {                      // next sample's activations, quantised once (src/vec.h:311)
+                        const unsigned char q = (unsigned char)quant_s8(a[s]);
+                        smem[L::xq + ((tid >> 2) * S + s) * 4 + (tid & 3)] = q;
+                        smem[L::xqT + (s * 96 + (tid >> 2)) * 4 + (tid & 3)] = q;
+                    } else {
+                        *(float *)(smem + L::hA + L::ha_off(tid >> 2) + s * 16 + (tid & 3) * 4) = a[s];
+                    }
                 }
             }
             __syncthreads();                                                   // B2
@@ -544,6 +656,51 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 const int g = r >> 3, ri = r & 7;
                 float zrh = sm_bbias[r] + sm_condb[s * RB + r];               // src/nnet.c:351
                 float rec = sm_bbias[RB + r];
+                if constexpr (I8) {
+                    typedef int i4 __attribute__((ext_vector_type(4)));
+                    zrh = zrh * QS;
+                    rec = rec * QS;
+                    // recurrent part: 16 quantised inputs = 4 blocks (src/vec.h:274-304)
+                    const i4 wr = ((const i4 *)(smem + L::brec))[r];
+                    const i4 hb = *(const i4 *)(smem + L::hBq + s * 16);
+                    {
+                        float d[4];
+                        dot4_cvt_x4(d, wr[0], wr[1], wr[2], wr[3], hb[0], hb[1], hb[2], hb[3]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rec = rec + d[k];
+                    }
+                    rec = rec * QS1;
+                    // input part: four blocks of this lane's row per 16-byte read; groups are padded to x4
+                    const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
+                    const int nq = (bend - bbeg) >> 2;
+                    const i4 *wq = (const i4 *)(smem + L::bw) + (bbeg >> 2) * 8 + ri;
+                    const unsigned char *xb = smem + L::xqT + s * 384;
+                    if (b_dense) {
+                        const i4 *xq4 = (const i4 *)xb;
+                        i4 w4 = wq[0], x4 = xq4[0];
+                        for (int q = 0; q < nq; ++q) {
+                            const i4 wn = wq[(q + 1) * 8], xn = xq4[q + 1];      // reads one quad ahead (padded / unused at the end)
+                            float d[4];
+                            dot4_cvt_x4(d, w4[0], w4[1], w4[2], w4[3], x4[0], x4[1], x4[2], x4[3]);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) zrh = zrh + d[k];
+                            w4 = wn; x4 = xn;
+                        }
+                    } else {
+                        const uint2 *offs = (const uint2 *)(sm_boff + bbeg);
+                        for (int q = 0; q < nq; ++q) {
+                            const i4 w4 = wq[q * 8];
+                            const uint2 o = offs[q];
+                            const int x0 = *(const int *)(xb + (o.x & 0xFFFFu)), x1 = *(const int *)(xb + (o.x >> 16));
+                            const int x2 = *(const int *)(xb + (o.y & 0xFFFFu)), x3 = *(const int *)(xb + (o.y >> 16));
+                            float d[4];
+                            dot4_cvt_x4(d, w4[0], w4[1], w4[2], w4[3], x0, x1, x2, x3);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) zrh = zrh + d[k];
+                        }
+                    }
+                    zrh = zrh * QS1;
+                } else {
                 // Each group's block list is padded to a multiple of 4 (zero weights) by the host.
                 // The loop is unrolled by 4 with a 4-deep register ring: block b+2 is fetched while
                 // block b feeds the dependent add chain (this phase is one wave per SIMD, so LDS
@@ -617,6 +774,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     wptr += 512;
                 }
 #undef LPCN_B_STEP
+                }
                 LPCN_PROF(8);      // GRU-B input mat-vec
                 // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
                 const float sg = lpcn_sigmoid(zrh + rec, sm_tansig);
@@ -626,7 +784,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 if (lane < NB) {
                     const float hold = sm_hB[s * NB + lane];
                     const float hnew = sg * hold + (1.f - sg) * hc_i;
-                    if ((live_mask >> s) & 1) sm_hB[s * NB + lane] = hnew;
+                    if ((live_mask >> s) & 1) {
+                        sm_hB[s * NB + lane] = hnew;
+                        if constexpr (I8) smem[L::hBq + s * NB + lane] = (unsigned char)quant_s8(hnew);
+                    }
                 }
             }
             __syncthreads();                                                   // B3
@@ -702,7 +863,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             }
             if (Ap->dbg && blockIdx.x == 0) {
                 float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE;
-                if (tid < NA) d[tid] = *(const float *)(smem + L::hA + L::ha_off(tid >> 2) + (tid & 3) * 4);
+                if (tid < NA) d[tid] = sm_hT[tid * S];
                 if (tid < NB) d[384 + tid] = sm_hB[tid];
             }
             __syncthreads();                                                   // B5
@@ -733,7 +894,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
             const int s = i / NA, n = i % NA;
             if (s < n_valid)
-                states[s0 + s].gru_a[n] = *(const float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4);
+                states[s0 + s].gru_a[n] = sm_hT[n * S + s];
         }
         for (int i = tid; i < S * NB; i += LPCN_WG_THREADS)
             if (i / NB < n_valid) states[s0 + i / NB].gru_b[i % NB] = sm_hB[i];

@@ -60,7 +60,7 @@ def test_check_model_accepts_and_rejects(blob_f32, blob_i8):
     rc, info = api.check_model(blob_f32)
     assert rc == 0 and info[:3] == [0, 1382, 576] and info[5] == 0 and 0 < info[3] <= 40
     rc, info = api.check_model(blob_i8)
-    assert rc == 1 and info[0] == 1
+    assert rc == 0 and info[:3] == [1, 1382, 576] and info[5] == 0 and 0 < info[3] <= 64      # int8 packing self-check
     assert api.check_model(blob_f32[:-64])[0] == -1                 # last record truncated
     assert api.check_model(b"")[0] == -1
     bad = bytearray(blob_f32)

@@ -283,6 +283,42 @@ def test_full_size_1024_streams_properties(blob_f32, golden, hip_lib):
     b.close()
 
 
-def test_int8_blob_is_refused_not_miscomputed(blob_i8, hip_lib):
-    with pytest.raises(api.LPCNetError):
-        api.LPCNetBatch(1, blob_i8)
+def test_int8_golden_reference_pcm(blob_i8, golden, hip_lib):
+    """config 4: the int8 (DOT_PROD) blob on the GPU == the reference's generic-C int8 build, bit for bit."""
+    T = int(golden["n_frames"])
+    for seed in (1000, 1001, 1002):
+        b = api.LPCNetBatch(1, blob_i8)
+        pcm = b.synthesize(feats_for([seed], T))
+        assert np.array_equal(pcm[0], golden[f"pcm_gi_{seed}"])
+        b.close()
+
+
+@pytest.mark.parametrize("S", [1, 2, 4])
+def test_int8_multi_stream_matches_oracle(blob_i8, S, hip_lib):
+    """int8 engine, streams-per-workgroup 1/2/4, ragged stream count, full state comparison."""
+    n, T = 7, 9
+    feats = feats_for(range(2100, 2100 + n), T)
+    want, states = oracle_run(blob_i8, feats)
+    b = api.LPCNetBatch(n, blob_i8)
+    b.streams_per_workgroup = S
+    got = b.synthesize(feats)
+    assert np.array_equal(got, want)
+    for s in range(n):
+        st = b.get_state(s)
+        _, _, ga, gb = states[s].nnet_state()
+        ls, le, dm, fc, rng = states[s].signal_state()
+        assert np.array_equal(np.array(st.gru_a, np.float32), ga) and np.array_equal(np.array(st.gru_b, np.float32), gb)
+        assert np.array_equal(np.array(st.last_sig, np.float32), ls) and st.last_exc == le and st.frame_count == fc
+        assert np.array_equal(np.array(st.rng, np.uint32), rng)
+    b.close()
+
+
+def test_int8_streaming_state_roundtrip(blob_i8, hip_lib):
+    """the quantised activations are rebuilt from the float state at every launch: split runs == one run."""
+    feats = feats_for([4100, 4101, 4102], 12)
+    b = api.LPCNetBatch(3, blob_i8)
+    whole = b.synthesize(feats)
+    b.reset()
+    parts = np.concatenate([b.synthesize(feats[:, :5]), b.synthesize(feats[:, 5:6]), b.synthesize(feats[:, 6:])], axis=1)
+    assert np.array_equal(whole, parts)
+    b.close()

@@ -11,7 +11,9 @@ def main():
     configs = [(1, 1), (256, 1), (512, 2), (1024, 4), (1024, 2), (1024, 1), (2048, 4), (4096, 4)]
     if len(sys.argv) > 2:
         configs = [tuple(int(x) for x in c.split(":")) for c in sys.argv[2].split(",")]
-    blob = synth.blob_bytes(synth.make_model())
+    flavour = os.environ.get("LPCN_FLAVOUR", "float")
+    blob = synth.blob_bytes(synth.make_model(flavour=flavour))
+    print("flavour", flavour)
     om = orc.OracleModel(blob)
     base = np.stack([synth.make_features(1000 + s, T) for s in range(8)])
     ref = np.stack([om.new_state().synthesize(base[s]) for s in range(8)])
@@ -30,8 +32,9 @@ def main():
         live = n * (T - 2) * 160
         print(f"n={n:5d} S={S} exact={ok} sample_kernel={ms_s:8.2f} ms frame_kernels={ms_f:6.2f} ms wall={wall*1e3:8.1f} ms "
               f"-> {live/(ms_s*1e-3)/1e6:8.2f} M samples/s (kernel), us/step={ms_s*1e3/((T-2)*160):6.2f} ", flush=True)
-        print("   per-wave clk/step [B1wait P2 P3tail P4 P5 | gather slots fcpre gruB]:")
-        for w in range(8): print("   wave", w, " ".join("%6.0f" % x for x in prof[w*12:w*12+11]), flush=True)
+        if prof.any():
+            print("   per-wave clk/step [B1wait P2 P3tail P4 P5 | gather slots fcpre gruB]:")
+            for w in range(8): print("   wave", w, " ".join("%6.0f" % x for x in prof[w*12:w*12+11]), flush=True)
         b.close()
 
 if __name__ == "__main__":
