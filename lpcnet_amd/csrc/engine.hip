@@ -111,15 +111,14 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     for (int wv = 0; wv < LPCN_WAVES; ++wv) {
         for (int k = 0; k < 4; ++k) bound[wv * 4 + k] = m->pk_a_bound[wv][k];
         for (int k = 0; k < 3; ++k) allh[wv * 3 + k] = m->pk_a_allh[wv][k];
-        bound[wv * 4 + 3] = nwv;
     }
 #define UP(T, field, src, count) if ((rc = upload<T>(e, &a.field, src, count))) return fail(rc)
     UP(int, a_row, m->pk_a_row, LPCN_WAVES * 3 * 64);
     UP(int, a_bound, bound, LPCN_WAVES * 4);
     UP(int, a_allh, allh, LPCN_WAVES * 3);
-    UP(float, emb_sig, m->pk_emb[0], (size_t)256 * LPCN_WG_THREADS * 4);
-    UP(float, emb_pred, m->pk_emb[1], (size_t)256 * LPCN_WG_THREADS * 4);
-    UP(float, emb_exc, m->pk_emb[2], (size_t)256 * LPCN_WG_THREADS * 4);
+    UP(float, emb_sig, m->pk_emb[0], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+    UP(float, emb_pred, m->pk_emb[1], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+    UP(float, emb_exc, m->pk_emb[2], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
     UP(float, a_bias1, m->a_bias + LPCN_ROWS_A, LPCN_ROWS_A);
     UP(float, a_diag, m->a_diag, LPCN_ROWS_A);
     if (m->is_int8) {

@@ -74,7 +74,7 @@ typedef struct lpcn_model_host {
     float   *pk_b_w;      /* GRU-B input weights re-blocked [blk][row-in-group 8][k 4] per group */
     int32_t *pk_b_start;  /* [6 groups + 1] first block of each group in pk_b_w                */
     uint8_t *pk_b_blk;    /* [nb_b] input block index per block                                */
-    float   *pk_emb[3];   /* sig/pred/exc tables re-ordered to [256][512 threads][4] (3 owned rows + pad) */
+    float   *pk_emb[3];   /* sig/pred/exc tables re-ordered to [256][3 slots][512 threads] */
 } lpcn_model_host;
 
 /* model_pack.c -------------------------------------------------------------------------------

@@ -94,13 +94,17 @@ static int pack_gru_a(lpcn_model_host *m)
     qsort(g, NG, sizeof(g[0]), cmp_group_desc);
 
     /* Slot -> wave assignment with a small cost model of the kernel (unit: items).
-     *  - candidate-only ("all-h") slots go first, one per wave: such a wave can start its item
-     *    chain before the embedding gather has landed;
-     *  - waves left without one pay ~10 items of exposed gather latency;
+     *  - candidate-only ("all-h") slots go first, one per wave: their rows start from bias +
+     *    diag*h alone, so such a wave runs them while the previous sample's leader work and the
+     *    embedding gather of the new sample are still in flight (~G items of time);
+     *  - waves without one idle until the gather has landed: both kinds pay max(first slot, G);
      *  - every slot costs ~2 items of begin/end work;
      *  - remaining slots: longest-processing-time on the wave cost;
-     *  - finally waves are renumbered so that the heaviest shares a SIMD with the lightest
-     *    (waves w and w+4 of a workgroup land on the same SIMD). */
+     *  - finally waves are renumbered by item count: the four with the fewest items become waves
+     *    0..3 (wave 0 leads the streams, wave 1 draws the random thresholds, waves 0..S-1 run
+     *    GRU-B: their extra duties fall into the time the others spend on items) and each shares
+     *    a SIMD with one of the busiest (waves w and w+4 of a workgroup land on the same SIMD). */
+    const int G = m->is_int8 ? 30 : 20;
     int slot_max[NSLOT], slot_allh[NSLOT], wave_of[NSLOT], nslots[LPCN_WAVES] = {0};
     int items[LPCN_WAVES] = {0}, cost[LPCN_WAVES] = {0};
     for (int s = 0; s < NSLOT; s++) {
@@ -114,23 +118,29 @@ static int pack_gru_a(lpcn_model_host *m)
         int best = -1;
         for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) { best = w; break; }
         if (best < 0) continue;
-        wave_of[s] = best; nslots[best] = 1; items[best] = slot_max[s]; cost[best] = slot_max[s] + 2;
+        wave_of[s] = best; nslots[best] = 1; items[best] = slot_max[s];
+        cost[best] = (slot_max[s] > G ? slot_max[s] : G) + 2;
     }
-    for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) cost[w] = 10;
+    for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) cost[w] = G;
+    int cap = 0;                                    /* items per wave = VGPRs: do not exceed the unavoidable maximum */
+    for (int s = 0; s < NSLOT; s++) cap += slot_max[s];
+    cap = (cap + LPCN_WAVES - 1) / LPCN_WAVES + 2;
+    if (cap < slot_max[0]) cap = slot_max[0];
     for (int s = 0; s < NSLOT; s++) {               /* pass 2: LPT (slots are in descending order) */
         if (wave_of[s] >= 0) continue;
         int best = -1;
-        for (int w = 0; w < LPCN_WAVES; w++)
-            if (nslots[w] < LPCN_MAX_SLOTS && (best < 0 || cost[w] < cost[best])) best = w;
+        for (int pass = 0; pass < 2 && best < 0; pass++)
+            for (int w = 0; w < LPCN_WAVES; w++)
+                if (nslots[w] < LPCN_MAX_SLOTS && (pass || items[w] + slot_max[s] <= cap) && (best < 0 || cost[w] < cost[best])) best = w;
         wave_of[s] = best; nslots[best]++; items[best] += slot_max[s]; cost[best] += slot_max[s] + 2;
     }
-    {   /* pass 3: renumber waves: rank by cost, pair rank i with rank 7-i on one SIMD */
+    {   /* pass 3: renumber waves: lightest -> wave 0, each paired with a heavy one on its SIMD */
         int order[LPCN_WAVES], newid[LPCN_WAVES];
         for (int w = 0; w < LPCN_WAVES; w++) order[w] = w;
         for (int i = 0; i < LPCN_WAVES; i++)
             for (int j = i + 1; j < LPCN_WAVES; j++)
-                if (cost[order[j]] > cost[order[i]]) { int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
-        for (int i = 0; i < LPCN_WAVES / 2; i++) { newid[order[i]] = i; newid[order[LPCN_WAVES - 1 - i]] = i + 4; }
+                if (items[order[j]] > items[order[i]]) { int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
+        for (int i = 0; i < LPCN_WAVES / 2; i++) { newid[order[LPCN_WAVES - 1 - i]] = i; newid[order[i]] = i + 4; }
         int items2[LPCN_WAVES];
         for (int w = 0; w < LPCN_WAVES; w++) items2[newid[w]] = items[w];
         for (int w = 0; w < LPCN_WAVES; w++) items[w] = items2[w];
@@ -180,19 +190,19 @@ static int pack_gru_a(lpcn_model_host *m)
         for (int k = fill[w]; k <= LPCN_MAX_SLOTS; k++) m->pk_a_bound[w][k] = cur[w];
         for (int k = fill[w]; k < LPCN_MAX_SLOTS; k++) m->pk_a_allh[w][k] = 1;
     }
-    /* Embedding tables re-ordered to the lane layout: E'[level][thread 0..511][4] holds, for the
-     * three rows a thread owns, the table entries of one mu-law level (4th float unused), so the
-     * per-sample gather is ONE 16-byte load per table and stream instead of three scattered dwords. */
+    /* Embedding tables re-ordered to the lane layout: E'[level][slot 0..2][thread 0..511] holds the
+     * table entry of the row thread t owns in slot k, so the per-sample gather of one slot is a
+     * fully coalesced 256-byte read per wave (2 KB per workgroup) per table and stream. */
     const float *src[3] = {m->emb_sig, m->emb_pred, m->emb_exc};
     for (int tb = 0; tb < 3; tb++) {
-        float *dst = (float *)calloc((size_t)256 * LPCN_WG_THREADS * 4, sizeof(float));
+        float *dst = (float *)calloc((size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS, sizeof(float));
         if (!dst) return -1;
         for (int v = 0; v < 256; v++)
             for (int w = 0; w < LPCN_WAVES; w++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int k = 0; k < LPCN_MAX_SLOTS; k++) {
                         int r = m->pk_a_row[(w * LPCN_MAX_SLOTS + k) * 64 + lane];
-                        dst[((size_t)v * LPCN_WG_THREADS + w * 64 + lane) * 4 + k] = r >= 0 ? src[tb][(size_t)v * LPCN_ROWS_A + r] : 0.f;
+                        dst[((size_t)v * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS + w * 64 + lane] = r >= 0 ? src[tb][(size_t)v * LPCN_ROWS_A + r] : 0.f;
                     }
         m->pk_emb[tb] = dst;
     }
@@ -417,7 +427,7 @@ int lpcn_model_selftest(const lpcn_model_host *m)
                 for (int t = 0; t < LPCN_WG_THREADS; t++)
                     for (int k = 0; k < LPCN_MAX_SLOTS; k++) {
                         int row = m->pk_a_row[((t >> 6) * LPCN_MAX_SLOTS + k) * 64 + (t & 63)];
-                        float e = m->pk_emb[tb][((size_t)v * LPCN_WG_THREADS + t) * 4 + k];
+                        float e = m->pk_emb[tb][((size_t)v * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS + t];
                         if (row >= 0 && e != src[tb][(size_t)v * LPCN_ROWS_A + row]) { rc = 6; goto done; }
                     }
     }

@@ -35,7 +35,7 @@
 
 struct LpcnSampleArgs {
     // model (device pointers)
-    const float *emb_sig, *emb_pred, *emb_exc;      // [256][512 threads][4]: lane-ordered embedding tables
+    const float *emb_sig, *emb_pred, *emb_exc;      // [256][3 slots][512 threads]: lane-ordered embedding tables
     const float4 *a_w;                              // [8][NW][64] float4 (fp32 blobs) or [8][NW][64] dwords of 4 int8 (int8 blobs)
     const uint8_t *a_blk;                           // [8][NW][64]
     const int *a_row;                               // [8][3][64]
@@ -106,7 +106,8 @@ template <int S> struct Lds {
     static constexpr int thr    = idx + S * 16;                     // [S][8] f32
     static constexpr int mask   = thr + S * 32;                     // [S][8] u64
     static constexpr int lead   = mask + S * 64;                    // [S][8] leader scalars (pred,deemph,exc,head,rng4)
-    static constexpr int condb  = lead + S * 32;                    // [S][48] f32
+    static constexpr int flag   = lead + S * 32;                    // [4] i32: sequence number of the newest published sample indices
+    static constexpr int condb  = flag + 16;                        // [S][48] f32
     static constexpr int lpc    = condb + S * RB * 4;               // [S][16] f32
     static constexpr int sig    = lpc + S * 64;                     // [S][16] f32 ring of past samples
     static constexpr int pcmbuf = sig + S * 64;                     // [S][160] i16
@@ -119,7 +120,7 @@ template <int S> struct Lds {
     static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
     static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
-    static constexpr int total(int nb_b, bool i8) { return bw + (nb_b + 8) * (i8 ? 32 : 128); }   // pad: the GRU-B pipeline reads ahead
+    static constexpr int total(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 16 : 8)) * (i8 ? 32 : 128); }   // pad: the GRU-B pipeline reads ahead
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
     static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
     static constexpr int xqT    = hA + 384 * S;                     // [S][96] dwords: the same, stream-major (GRU-B input)
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     }
     int b1 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 1]);
     int b2 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 2]);
+    int b3 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 3]);   // this wave's item count
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
     const bool b_dense = Ap->b_dense != 0;
 
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         }
         const auto *bw = as_global(Ap->b_w);
         constexpr int BW_DW = I8 ? 8 : 32;                  // dwords per GRU-B block
-        for (int i = tid; i < (nb_b + 8) * BW_DW; i += LPCN_WG_THREADS) ((uint32_t *)(smem + L::bw))[i] = i < nb_b * BW_DW ? ((const LPCN_GLOBAL uint32_t *)bw)[i] : 0u;
+        for (int i = tid; i < (nb_b + (I8 ? 16 : 8)) * BW_DW; i += LPCN_WG_THREADS) ((uint32_t *)(smem + L::bw))[i] = i < nb_b * BW_DW ? ((const LPCN_GLOBAL uint32_t *)bw)[i] : 0u;
         for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
             const int s = i / NA, n = i % NA;
             const float hv0 = states[stream_of(s)].gru_a[n];
@@ -329,8 +331,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     }
     __syncthreads();
 
-    // leader: open the next sample (prediction, mu-law indices, tree thresholds)
-    auto start_sample = [&](const int ls, const bool live) {
+    // Opening a sample has two independent halves that run on different waves:
+    //  * wave 0, lane s ("leader" of stream s): LPC prediction and the three mu-law indices of the
+    //    embedding gather (src/lpcnet.c:252-254), published through sm_idx + sm_flag;
+    //  * wave 1, lane s: the two KISS99 words that become the 8 tree thresholds (src/nnet.c:178-184).
+    auto start_indices = [&](const int ls, const bool live) {
         int *li = (int *)sm_lead + ls * 8;
         if (live) {
             const int head = li[3];
@@ -339,28 +344,46 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             for (int j = 0; j < LPCN_LPC_ORDER; ++j)                              // src/lpcnet.c:252
                 pred = pred - sm_sig[ls * LPCN_LPC_ORDER + ((head + j) & 15)] * sm_lpc[ls * LPCN_LPC_ORDER + j];
             sm_lead[ls * 8 + 0] = pred;
-            sm_idx[ls * 4 + 0] = lpcn_lin2ulaw(sm_sig[ls * LPCN_LPC_ORDER + head]);
-            sm_idx[ls * 4 + 1] = lpcn_lin2ulaw(pred);
-            sm_idx[ls * 4 + 2] = li[2];
-            // thresholds for the 8 tree levels: two KISS99 words (src/nnet.c:178-184)
-            uint32_t rng[4] = {(uint32_t)li[4], (uint32_t)li[5], (uint32_t)li[6], (uint32_t)li[7]};
-            const uint32_t r0 = lpcn_kiss99(rng), r1 = lpcn_kiss99(rng);
-            li[4] = (int)rng[0]; li[5] = (int)rng[1]; li[6] = (int)rng[2]; li[7] = (int)rng[3];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                sm_thr[ls * 8 + b] = sm_logit[(r0 >> (8 * b)) & 0xFF];
-                sm_thr[ls * 8 + 4 + b] = sm_logit[(r1 >> (8 * b)) & 0xFF];
-            }
+            // (sig, pred, exc) mu-law indices packed into one word per stream
+            sm_idx[ls] = lpcn_lin2ulaw(sm_sig[ls * LPCN_LPC_ORDER + head]) | (lpcn_lin2ulaw(pred) << 8) | (li[2] << 16);
         } else {
-            sm_idx[ls * 4 + 0] = 0; sm_idx[ls * 4 + 1] = 0; sm_idx[ls * 4 + 2] = 0;
+            sm_idx[ls] = 0;
         }
-        sm_idx[ls * 4 + 3] = live ? 1 : 0;
+        sm_idx[S + ls] = live ? 1 : 0;
     };
+    auto draw_thresholds = [&](const int ls) {
+        int *li = (int *)sm_lead + ls * 8;
+        uint32_t rng[4] = {(uint32_t)li[4], (uint32_t)li[5], (uint32_t)li[6], (uint32_t)li[7]};
+        const uint32_t r0 = lpcn_kiss99(rng), r1 = lpcn_kiss99(rng);
+        li[4] = (int)rng[0]; li[5] = (int)rng[1]; li[6] = (int)rng[2]; li[7] = (int)rng[3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            sm_thr[ls * 8 + b] = sm_logit[(r0 >> (8 * b)) & 0xFF];
+            sm_thr[ls * 8 + 4 + b] = sm_logit[(r1 >> (8 * b)) & 0xFF];
+        }
+    };
+    // The sample loop has no barrier between the leader's work and the next sample's GRU-A: the
+    // other waves run ahead into the rows that need no gathered input and pick the new indices
+    // up through this flag (LDS operations of one wave complete in order).
+    int seq = 0;                                             // samples opened so far (identical in every wave)
+    const uint32_t flag_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::flag);
+    auto publish_indices = [&]() {                           // after the sm_idx writes of the same lane
+        asm volatile("ds_write_b32 %0, %1" :: "v"(flag_addr), "v"(seq) : "memory");
+    };
+    auto wait_indices = [&]() {
+        int v;
+        do {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v != seq) __builtin_amdgcn_s_sleep(1);
+        } while (v != seq);
+    };
+    if (tid0 == 0) *(int *)(smem + L::flag) = 0;
 
 #if LPCN_ENABLE_PROF      // per-phase shader-clock accounting (profiling builds only: it costs VGPRs)
     unsigned long long *const prof = Ap->prof;
     unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool profiling = prof != nullptr && blockIdx.x == 0 && (tid0 & 63) == 0;
+    const bool profiling = prof != nullptr && blockIdx.x == 0;      // wave-uniform: the counters stay in SGPRs
 #define LPCN_PROF(slot) do { if (profiling) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[slot] += now_ - tprev; tprev = now_; } } while (0)
 #else
 #define LPCN_PROF(slot) do { } while (0)
@@ -379,24 +402,26 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             if (tid < S * RB) sm_condb[tid] = cb[((size_t)stream_of(tid / RB) * nf + f) * RB + tid % RB];
             if (tid < S * LPCN_LPC_ORDER)
                 sm_lpc[tid] = lp[((size_t)stream_of(tid / LPCN_LPC_ORDER) * nf + f) * LPCN_LPC_ORDER + tid % LPCN_LPC_ORDER];
-            if (tid < S) {
-                const int lstream = stream_of(tid);
+            if ((tid & 63) < S && tid < 128) {                    // lanes 0..S-1 of wave 0 (leaders) and wave 1 (thresholds)
+                const int lstream = stream_of(tid & 63);
                 const int fc_ref = Ap->fc_base ? as_global(Ap->fc_base)[lstream] : states[lstream].frame_count;
                 int fc = Ap->fc_advance ? fc_ref + f + 1 : fc_ref;
                 if (fc > 1000) fc = 1000;
                 live = fc > LPCN_FEATURES_DELAY;                 // src/lpcnet.c:239-243
-                if (preload > 0) {                                // teacher forcing reads the caller's samples
+                if (preload > 0 && tid < S) {                     // teacher forcing reads the caller's samples
                     const auto *pin = as_global(Ap->pcm) + (size_t)lstream * (size_t)Ap->pcm_stride + (size_t)f * LPCN_FRAME_SIZE;
                     for (int i = 0; i < preload; ++i) sm_pcm[tid * LPCN_FRAME_SIZE + i] = pin[i];
                 }
             }
         }
         __syncthreads();        // sm_lpc visible to the leaders
-        if (tid0 < S) start_sample(tid0, live);
+        ++seq;
+        if (tid0 < S) { start_indices(tid0, live); publish_indices(); }
+        if (tid0 >= 64 && tid0 < 64 + S && live) draw_thresholds(tid0 - 64);
         __syncthreads();
         int live_mask = 0;                                   // bit s: stream s produces samples in this frame
 #pragma unroll
-        for (int s = 0; s < S; ++s) live_mask |= (sm_idx[s * 4 + 3] ? 1 : 0) << s;
+        for (int s = 0; s < S; ++s) live_mask |= (sm_idx[S + s] ? 1 : 0) << s;
         live_mask = __builtin_amdgcn_readfirstlane(live_mask);
         const int any_live = live_mask;
         if (!any_live) {                                     // start-up frames: zeros, no state change
@@ -413,14 +438,24 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             // ---- embedding gather: one 16-byte row per table and stream holds the entries of this
             // lane's three rows.  Register pressure is the binding constraint of this kernel (the
             // weights own 4*NW VGPRs), so the gathered values are consumed slot by slot.
-            float ge[3][3][S];                               // sig / pred / exc entries (third set: light waves only)
+            // (zero-initialised: otherwise the compiler carries the arrays around the sample loop as live values)
+            float ge[3][3][S] = {};                          // sig / pred / exc entries (third set: light waves only)
+            int gi[S] = {};                                  // this sample's mu-law indices, packed (scalar registers)
+            auto load_indices = [&]() {                      // one LDS read for all streams, then the loads go back to back
+                typename XVec<S>::type v = *(const typename XVec<S>::type *)sm_idx;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if constexpr (S == 1) gi[s] = __builtin_amdgcn_readfirstlane(v);
+                    else gi[s] = __builtin_amdgcn_readfirstlane(v[s]);
+                }
+            };
             auto gather = [&](const int k, const int set) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const int i_sig = sm_idx[s * 4 + 0], i_pred = sm_idx[s * 4 + 1], i_exc = sm_idx[s * 4 + 2];
-                    ge[set][0][s] = emb_sig[((size_t)i_sig * LPCN_WG_THREADS + tid0) * 4 + k];
-                    ge[set][1][s] = emb_pred[((size_t)i_pred * LPCN_WG_THREADS + tid0) * 4 + k];
-                    ge[set][2][s] = emb_exc[((size_t)i_exc * LPCN_WG_THREADS + tid0) * 4 + k];
+                    // the mu-law indices are workgroup-uniform: scalar row base + lane offset
+                    ge[set][0][s] = (emb_sig + (size_t)((gi[s] & 0xFF) * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS)[tid0];
+                    ge[set][1][s] = (emb_pred + (size_t)(((gi[s] >> 8) & 0xFF) * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS)[tid0];
+                    ge[set][2][s] = (emb_exc + (size_t)((gi[s] >> 16) * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS)[tid0];
                 }
             };
             LPCN_PROF(5);
@@ -477,14 +512,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 }
             };
             // Waves whose first slot holds only candidate rows (the big ones) start it from
-            // bias + diag*h alone and resolve the gather-dependent values slot by slot at fixed item
-            // position JSTAR (the gathers get JSTAR items to land); the light waves resolve
-            // everything up front.  jmode is wave-uniform.
-            constexpr int JSTAR = 9;
-            const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 > JSTAR) ? 1 : 0);
-            gather(1, 0);
-            gather(2, 1);
+            // bias + diag*h alone: they need neither the new sample's indices nor the gathered rows
+            // for that, so they run ahead while wave 0 still finishes the previous sample.  They
+            // poll for the indices at item JG, issue the gathers, and resolve the gather-dependent
+            // start values at item JSTAR (<= their first slot boundary).  The other waves wait for
+            // the indices and resolve everything up front.  jmode is wave-uniform.
+            constexpr int JG = I8 ? 8 : 4, JSTAR = 18;
+            const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR) ? 1 : 0);
             if (jmode == 0) {
+                wait_indices();
+                load_indices();
+                gather(1, 0);
+                gather(2, 1);
                 gather(0, 2);
                 row_init(1, 0, false);
                 row_init(2, 1, false);
@@ -500,15 +539,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     if constexpr (I8) acc[s] = acc[s] * QS;
                 }
             }
+            LPCN_PROF(10);     // gather issue + (light waves) wait + start values
 #pragma unroll
             for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
             LPCN_REMAT_S(b1);
             LPCN_REMAT_S(b2);
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                if (j == 14) LPCN_PROF(10);
-                if (j == 18) LPCN_PROF(9);       // items 14..17 (no mid-phase, usually no boundary)
+            LPCN_REMAT_S(b3);
+            auto item = [&](const int j) {
                 if (j == JSTAR) { if (jmode) { row_init(1, 0, false); row_init(2, 1, false); gather(0, 0); } }
+                if (j >= b3) return;                         // wave-uniform: only this wave's own items
                 // wave-uniform slot boundaries (a slot may be empty: b1 == b2, or b1 == 0)
                 if (j == b1) row_swap(0, 1);
                 if (j == b2) row_swap(1, 2);
@@ -548,14 +587,20 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     }
                 }
                 }
-            }
+            };
+#pragma unroll
+            for (int j = 0; j < JG && j < NW; ++j) item(j);
+            if (jmode) { wait_indices(); load_indices(); gather(1, 0); gather(2, 1); }      // between two fully unrolled halves
+#pragma unroll
+            for (int j = JG; j < NW; ++j) item(j);
+            LPCN_PROF(9);      // item loop (incl. the mid-phase start values of the heavy waves)
             // close whichever slot is still open; slots that start exactly at NW have no items
             // (b1 <= b2 <= NW; items past a wave's last real item carry zero weights)
-            if (b1 >= NW) {
+            if (b1 >= b3) {
                 row_swap(0, 1);
                 row_swap(1, 2);
                 row_store(2);
-            } else if (b2 >= NW) {
+            } else if (b2 >= b3) {
                 row_swap(1, 2);
                 row_store(2);
             } else {
@@ -582,55 +627,46 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             int tid = tid0;
             LPCN_REMAT_V(tid);
             // ------------------------------------------------------------ P2: GRU-A gates --
-            // (a) update/reset gates: sigmoid over the 768 rows x S streams, rows spread over all lanes
+            // One work item per (neuron, stream): update/reset sigmoids, candidate tanh and the blend
+            // (src/nnet.c:441-447).  sm_pre / sm_inh / sm_hT are [row][stream], so item i = n*S + s is
+            // simply element i of each gate's third: consecutive lanes touch consecutive words.
             {
-                constexpr int NQ = (2 * NA + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
-                float v[NQ][S];
+                constexpr int NI = NA * S;                                     // items
+                constexpr int NQ = (NI + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
+                float z[NQ], rg[NQ], a[NQ], hold[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int r = tid + q * LPCN_WG_THREADS;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) v[q][s] = r < 2 * NA ? sm_pre[r * S + s] : 0.f;
+                    const int i = tid + q * LPCN_WG_THREADS;
+                    const int ic = i < NI ? i : 0;
+                    z[q] = sm_pre[ic];
+                    rg[q] = sm_pre[NI + ic];
+                    a[q] = sm_pre[2 * NI + ic];
+                    hold[q] = sm_hT[ic];
                 }
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int s = 0; s < S; ++s) v[q][s] = lpcn_sigmoid(v[q][s], sm_tansig);
+                for (int q = 0; q < NQ; ++q) { z[q] = lpcn_sigmoid(z[q], sm_tansig); rg[q] = lpcn_sigmoid(rg[q], sm_tansig); }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int r = tid + q * LPCN_WG_THREADS;
-                    if (r < 2 * NA) {
-#pragma unroll
-                        for (int s = 0; s < S; ++s) sm_pre[r * S + s] = v[q][s];
-                    }
-                }
-            }
-            __syncthreads();
-            // (b) candidate state and blend, one lane per neuron, S streams each (src/nnet.c:443-447)
-            if (tid < NA) {
-                float z[S], a[S], hold[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    z[s] = sm_pre[tid * S + s];
-                    a[s] = sm_pre[(2 * NA + tid) * S + s] * sm_pre[(NA + tid) * S + s] + sm_inh[tid * S + s];
-                    hold[s] = sm_hT[tid * S + s];
+                    const int i = tid + q * LPCN_WG_THREADS;
+                    a[q] = a[q] * rg[q] + sm_inh[i < NI ? i : 0];
                 }
 #pragma unroll
-                for (int s = 0; s < S; ++s) a[s] = lpcn_tanh(a[s], sm_tansig);
+                for (int q = 0; q < NQ; ++q) a[q] = lpcn_tanh(a[q], sm_tansig);
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float hnew = z[s] * hold[s] + (1.f - z[s]) * a[s];      // src/nnet.c:447
-                    a[s] = ((live_mask >> s) & 1) ? hnew : hold[s];
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    sm_hT[tid * S + s] = a[s];
-                    if constexpr (I8) {                      // next sample's activations, quantised once (src/vec.h:311)
-                        const unsigned char q = (unsigned char)quant_s8(a[s]);
-                        smem[L::xq + ((tid >> 2) * S + s) * 4 + (tid & 3)] = q;
-                        smem[L::xqT + (s * 96 + (tid >> 2)) * 4 + (tid & 3)] = q;
-                    } else {
-                        *(float *)(smem + L::hA + L::ha_off(tid >> 2) + s * 16 + (tid & 3) * 4) = a[s];
+                for (int q = 0; q < NQ; ++q) {
+                    const int i = tid + q * LPCN_WG_THREADS;
+                    const int n = i / S, s = i % S;
+                    const float hnew = z[q] * hold[q] + (1.f - z[q]) * a[q];      // src/nnet.c:447
+                    const float hv = ((live_mask >> s) & 1) ? hnew : hold[q];
+                    if (i < NI) {
+                        sm_hT[i] = hv;
+                        if constexpr (I8) {                  // next sample's activations, quantised once (src/vec.h:311)
+                            const unsigned char qv = (unsigned char)quant_s8(hv);
+                            smem[L::xq + ((n >> 2) * S + s) * 4 + (n & 3)] = qv;
+                            smem[L::xqT + (s * 96 + (n >> 2)) * 4 + (n & 3)] = qv;
+                        } else {
+                            *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv;
+                        }
                     }
                 }
             }
@@ -676,16 +712,29 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     const i4 *wq = (const i4 *)(smem + L::bw) + (bbeg >> 2) * 8 + ri;
                     const unsigned char *xb = smem + L::xqT + s * 384;
                     if (b_dense) {
+                        // all 96 input blocks in order: 24 quads, software-pipelined in batches of 4 quads
+                        // (8 LDS reads in flight while the previous batch feeds the dependent add chain)
                         const i4 *xq4 = (const i4 *)xb;
-                        i4 w4 = wq[0], x4 = xq4[0];
-                        for (int q = 0; q < nq; ++q) {
-                            const i4 wn = wq[(q + 1) * 8], xn = xq4[q + 1];      // reads one quad ahead (padded / unused at the end)
-                            float d[4];
-                            dot4_cvt_x4(d, w4[0], w4[1], w4[2], w4[3], x4[0], x4[1], x4[2], x4[3]);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) zrh = zrh + d[k];
-                            w4 = wn; x4 = xn;
+                        i4 wA[4], xA[4], wB[4], xB[4];
+#define LPCN_LDQ(W, X, Q0) _Pragma("unroll") for (int k = 0; k < 4; ++k) { W[k] = wq[((Q0) + k) * 8]; X[k] = xq4[(Q0) + k]; }
+#define LPCN_CPQ(W, X) _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                          \
+                            float d[4];                                                                      \
+                            dot4_cvt_x4(d, W[k][0], W[k][1], W[k][2], W[k][3], X[k][0], X[k][1], X[k][2], X[k][3]); \
+                            zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3]; }
+                        LPCN_LDQ(wA, xA, 0)
+#pragma unroll 1
+                        for (int q = 0; q < 24; q += 8) {
+                            LPCN_LDQ(wB, xB, q + 4)
+                            __builtin_amdgcn_sched_barrier(0);
+                            LPCN_CPQ(wA, xA)
+                            __builtin_amdgcn_sched_barrier(0);
+                            LPCN_LDQ(wA, xA, q + 8)          // past the end on the last trip: padded / unused
+                            __builtin_amdgcn_sched_barrier(0);
+                            LPCN_CPQ(wB, xB)
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+#undef LPCN_LDQ
+#undef LPCN_CPQ
                     } else {
                         const uint2 *offs = (const uint2 *)(sm_boff + bbeg);
                         for (int q = 0; q < nq; ++q) {
@@ -702,78 +751,56 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     zrh = zrh * QS1;
                 } else {
                 // Each group's block list is padded to a multiple of 4 (zero weights) by the host.
-                // The loop is unrolled by 4 with a 4-deep register ring: block b+2 is fetched while
-                // block b feeds the dependent add chain (this phase is one wave per SIMD, so LDS
-                // latency must be hidden by software).  sm_boff holds LDS byte offsets of the input
-                // blocks, four u16 per 8-byte read.
+                // This phase runs one wave per SIMD, so latency must be hidden by software, and the
+                // per-wave LDS issue rate (~25 clk per instruction) is as scarce as the dependent add
+                // chain (4 adds per block).  The four rows of a lane quad belong to the same row group
+                // and the same stream, so they need the same state blocks: lane k of the quad fetches
+                // block 4q+k and the other three rows take it through DPP quad broadcasts folded into
+                // the multiplies -- 1.25 LDS instructions per block instead of 2.
+                // Pipeline: weights are fetched 3 blocks ahead (ring of 4), the state quad one quad
+                // ahead, products are formed one block ahead of the running sum; scheduling barriers
+                // pin one multiply into the shadow of every dependent add.  Reads past the end of a
+                // group fetch valid (unused) LDS data; the host pads the arrays.
                 const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
                 const int nq = (bend - bbeg) >> 2;                          // groups of 4 blocks
                 // recurrent part first: an independent 16-term chain (src/nnet.c:356-361)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
-                // Software pipeline: loads for block b+2 are issued, products of block b+1 are formed
-                // (two packed multiplies) and the running sum takes the products of block b -- pinned with
-                // scheduling barriers so that every dependent add has independent work in its shadow.
-                // Reads past the end of a group fetch valid (unused) LDS data; the host pads the arrays.
-                typedef float f2 __attribute__((ext_vector_type(2)));
                 const unsigned char *wptr = smem + L::bw + (bbeg * 8 + ri) * 16;   // this lane's row, block 0 of its group
                 const unsigned char *hbase = smem + L::hA + s * 16;
-                const uint2 *offs = (const uint2 *)(sm_boff + bbeg);
+                const int k4 = lane & 3;
+                const unsigned short *offk = sm_boff + bbeg + k4;           // LDS offset of the block this lane fetches, per quad
                 auto ldw = [&](int byte_off) { return *(const float4 *)(wptr + byte_off); };
-                auto ldh = [&](unsigned o) { return *(const float4 *)(hbase + o); };
-                uint2 o_cur = offs[0], o_nxt = offs[1];
-                float4 wa = ldw(0), ha = ldh(o_cur.x & 0xFFFFu);
-                float4 wb = ldw(128), hb = ldh(o_cur.x >> 16);
-                f2 pl = (f2){wa.x, wa.y} * (f2){ha.x, ha.y}, ph = (f2){wa.z, wa.w} * (f2){ha.z, ha.w};
-#define LPCN_B_STEP(WN, HN, WLOAD, HLOAD)                                                               \
+                auto ldh = [&](int q) { return *(const float4 *)(hbase + offk[4 * q]); };
+                float4 wr0 = ldw(0), wr1 = ldw(128), wr2 = ldw(256), wr3;
+                float4 hq = ldh(0), hn;
+                unsigned off_n = offk[4];
+                float p0 = wr0.x * quad_bcast<0>(hq.x), p1 = wr0.y * quad_bcast<0>(hq.y);
+                float p2 = wr0.z * quad_bcast<0>(hq.z), p3 = wr0.w * quad_bcast<0>(hq.w);
+#define LPCN_SB __builtin_amdgcn_sched_barrier(0)
+                // accumulate block b (p0..p3), form products of block b+1 from (WN, HK-th lane of HQ), fetch block b+3 into WL
+#define LPCN_B_STEP(WL, WOFF, WN, HQ, HK, EXTRA)                                                        \
                 {                                                                                       \
-                    const float4 wl_ = WLOAD, hl_ = HLOAD;                                              \
-                    __builtin_amdgcn_sched_barrier(0);                                                  \
-                    const f2 ql_ = (f2){WN.x, WN.y} * (f2){HN.x, HN.y};                                 \
-                    __builtin_amdgcn_sched_barrier(0);                                                  \
-                    zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0);                                \
-                    zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);                                \
-                    const f2 qh_ = (f2){WN.z, WN.w} * (f2){HN.z, HN.w};                                 \
-                    __builtin_amdgcn_sched_barrier(0);                                                  \
-                    zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0);                                \
-                    zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);                                \
-                    pl = ql_; ph = qh_; WN = wl_; HN = hl_;                                             \
+                    WL = ldw(WOFF);                                                                     \
+                    EXTRA                                                                               \
+                    LPCN_SB;                                                                            \
+                    zrh = zrh + p0; LPCN_SB; const float t0_ = WN.x * quad_bcast<HK>(HQ.x); LPCN_SB;    \
+                    zrh = zrh + p1; LPCN_SB; const float t1_ = WN.y * quad_bcast<HK>(HQ.y); LPCN_SB;    \
+                    zrh = zrh + p2; LPCN_SB; const float t2_ = WN.z * quad_bcast<HK>(HQ.z); LPCN_SB;    \
+                    zrh = zrh + p3; LPCN_SB; const float t3_ = WN.w * quad_bcast<HK>(HQ.w); LPCN_SB;    \
+                    p0 = t0_; p1 = t1_; p2 = t2_; p3 = t3_;                                             \
                 }
                 for (int q = 0; q < nq; ++q) {
-                    // in flight: (wa,ha) = block 4q with products (pl,ph); (wb,hb) = block 4q+1
-                    // each step: load block +2, multiply block +1, add block +0; WN/HN name the +1 block
-                    { const float4 w2 = ldw(256), h2 = ldh(o_cur.y & 0xFFFFu);
-                      __builtin_amdgcn_sched_barrier(0);
-                      const f2 ql_ = (f2){wb.x, wb.y} * (f2){hb.x, hb.y}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
-                      const f2 qh_ = (f2){wb.z, wb.w} * (f2){hb.z, hb.w}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
-                      pl = ql_; ph = qh_; wa = w2; ha = h2; }
-                    { const float4 w3 = ldw(384), h3 = ldh(o_cur.y >> 16);
-                      __builtin_amdgcn_sched_barrier(0);
-                      const f2 ql_ = (f2){wa.x, wa.y} * (f2){ha.x, ha.y}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
-                      const f2 qh_ = (f2){wa.z, wa.w} * (f2){ha.z, ha.w}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
-                      pl = ql_; ph = qh_; wb = w3; hb = h3; }
-                    { const float4 w4 = ldw(512), h4 = ldh(o_nxt.x & 0xFFFFu);
-                      __builtin_amdgcn_sched_barrier(0);
-                      const f2 ql_ = (f2){wb.x, wb.y} * (f2){hb.x, hb.y}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
-                      const f2 qh_ = (f2){wb.z, wb.w} * (f2){hb.z, hb.w}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
-                      pl = ql_; ph = qh_; wa = w4; ha = h4; }
-                    { const float4 w5 = ldw(640), h5 = ldh(o_nxt.x >> 16);
-                      o_cur = o_nxt; o_nxt = offs[q + 2];
-                      __builtin_amdgcn_sched_barrier(0);
-                      const f2 ql_ = (f2){wa.x, wa.y} * (f2){ha.x, ha.y}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + pl.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + pl.y; __builtin_amdgcn_sched_barrier(0);
-                      const f2 qh_ = (f2){wa.z, wa.w} * (f2){ha.z, ha.w}; __builtin_amdgcn_sched_barrier(0);
-                      zrh = zrh + ph.x; __builtin_amdgcn_sched_barrier(0); zrh = zrh + ph.y; __builtin_amdgcn_sched_barrier(0);
-                      pl = ql_; ph = qh_; wb = w5; hb = h5; }
+                    // entering: p = products of block 4q; wr1, wr2 = weights of blocks 4q+1, 4q+2; hq = state quad q
+                    LPCN_B_STEP(wr3, 384, wr1, hq, 1, hn = *(const float4 *)(hbase + off_n); off_n = offk[4 * q + 8];)
+                    LPCN_B_STEP(wr0, 512, wr2, hq, 2, )
+                    LPCN_B_STEP(wr1, 640, wr3, hq, 3, )
+                    LPCN_B_STEP(wr2, 768, wr0, hn, 0, )
+                    hq = hn;
                     wptr += 512;
                 }
 #undef LPCN_B_STEP
+#undef LPCN_SB
                 }
                 LPCN_PROF(8);      // GRU-B input mat-vec
                 // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
@@ -814,7 +841,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             LPCN_PROF(3);
 
             // ------------------------------------------------ P5: leader finishes the sample --
+            // Not a workgroup phase: only wave 0 (lane s = stream s) and wave 1 (thresholds of the next
+            // sample) work here; everybody else is already in the next sample's GRU-A.
+            const bool more = smp + 1 < frame_len;
+            if (more) ++seq;
             if (tid < S) {
+                float pcm = 0.f, deemph = 0.f;
+                int exc = 0;
                 if (live) {
                     const unsigned long long *mk = sm_mask + tid * 8;
                     const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
@@ -831,12 +864,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                         else { const int q = (i >> 5) & 3; mw = q == 0 ? m4 : (q == 1 ? m5 : (q == 2 ? m6 : m7)); }
                         val = (val << 1) | (int)((mw >> (2 * (i & 31))) & 1ull);
                     }
-                    int exc = val;
+                    exc = val;
                     int *li = (int *)sm_lead + tid * 8;
                     const float pred = sm_lead[tid * 8 + 0];
-                    float deemph = sm_lead[tid * 8 + 1];
+                    deemph = sm_lead[tid * 8 + 1];
                     int head = li[3];
-                    float pcm;
                     if (smp < preload) {                                        // src/lpcnet.c:256-258
                         const float x = (float)sm_pcm[tid * LPCN_FRAME_SIZE + smp];
                         exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
@@ -848,29 +880,39 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     sm_sig[tid * LPCN_LPC_ORDER + head] = pcm;
                     li[3] = head;
                     li[2] = exc;
-                    pcm = pcm + 0.85f * deemph;
-                    deemph = pcm;
-                    sm_lead[tid * 8 + 1] = deemph;
-                    if (smp >= preload) sm_pcm[tid * LPCN_FRAME_SIZE + smp] = (short)lpcn_round_pcm(pcm);
+                }
+                if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live) {
+                    float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
+                    d[1] = (float)(sm_idx[0] & 0xFF); d[2] = (float)((sm_idx[0] >> 8) & 0xFF);
+                }
+                // the next sample's indices first: the other waves are waiting for them
+                if (more) { start_indices(tid, live); publish_indices(); }
+                if (live) {
                     if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
                         float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
-                        d[0] = (float)exc; d[1] = (float)sm_idx[0]; d[2] = (float)sm_idx[1]; d[3] = pcm; d[4] = pred;
+                        d[0] = (float)exc; d[3] = pcm + 0.85f * deemph; d[4] = sm_lead[tid * 8 + 0];
                     }
+                    pcm = pcm + 0.85f * deemph;
+                    sm_lead[tid * 8 + 1] = pcm;                                 // de-emphasis memory
+                    if (smp >= preload) sm_pcm[tid * LPCN_FRAME_SIZE + smp] = (short)lpcn_round_pcm(pcm);
                 } else {
                     sm_pcm[tid * LPCN_FRAME_SIZE + smp] = 0;
                 }
-                if (smp + 1 < frame_len) start_sample(tid, live);
             }
+            if (more && tid >= 64 && tid < 64 + S && live) draw_thresholds(tid - 64);
             if (Ap->dbg && blockIdx.x == 0) {
                 float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE;
                 if (tid < NA) d[tid] = sm_hT[tid * S];
                 if (tid < NB) d[384 + tid] = sm_hB[tid];
             }
-            __syncthreads();                                                   // B5
+            // no workgroup barrier here (see above); keep the compiler from mixing the two samples' code
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             LPCN_PROF(4);
         }
 
         // ---- flush the frame's PCM (S*160 samples, coalesced)
+        __syncthreads();        // the leaders' last samples
         {
             auto *out = as_global_rw(Ap->pcm);
             const size_t pstride = (size_t)Ap->pcm_stride;
@@ -883,7 +925,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     }
 
 #if LPCN_ENABLE_PROF
-    if (profiling) {
+    if (profiling && (tid0 & 63) == 0) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) prof[(tid0 >> 6) * 12 + i] += pt[i];
     }
