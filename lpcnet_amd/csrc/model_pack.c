@@ -158,37 +158,52 @@ static int pack_gru_a(lpcn_model_host *m)
     if ((!m->pk_a_w && !m->pk_a_wq) || !m->pk_a_blk || !m->pk_a_row) return -1;
     for (int i = 0; i < LPCN_WAVES * LPCN_MAX_SLOTS * 64; i++) m->pk_a_row[i] = -1;
 
-    int fill[LPCN_WAVES] = {0}, cur[LPCN_WAVES] = {0};
-    for (int w = 0; w < LPCN_WAVES; w++)
-        for (int k = 0; k <= LPCN_MAX_SLOTS; k++) m->pk_a_bound[w][k] = 0;
-    for (int s = 0; s < NSLOT; s++) {
-        int w = wave_of[s], k = fill[w]++, j0 = cur[w], allh = 1;
-        m->pk_a_bound[w][k] = j0;
-        for (int q = 0; q < 8; q++) {
-            const row_group *rg = &g[8 * s + q];
-            if (rg->group * 8 < 2 * LPCN_N_A) allh = 0;
-            for (int r = 0; r < 8; r++) {
-                int lane = 8 * q + r;
-                m->pk_a_row[(w * LPCN_MAX_SLOTS + k) * 64 + lane] = rg->group * 8 + r;
-                for (int j = 0; j < rg->count; j++) {
-                    size_t item = ((size_t)w * nw + (j0 + j)) * 64 + lane;
-                    if (m->is_int8) {      /* int8 block = [out 8][in 4] (dump_lpcnet.py:106): the row's 4 bytes are one dword */
-                        const signed char *blkq = (const signed char *)m->a_w + (size_t)(rg->first_block + j) * 32;
-                        memcpy(&m->pk_a_wq[item], blkq + r * 4, 4);
-                    } else {               /* float block = [in 4][out 8] (dump_lpcnet.py:107) */
-                        const float *blkw = m->a_w + (size_t)(rg->first_block + j) * 32;
-                        for (int c = 0; c < 4; c++) m->pk_a_w[item * 4 + c] = blkw[c * 8 + r];
-                    }
-                    m->pk_a_blk[item] = (uint8_t)(rg->pos[j] >> 2);
-                }
-            }
-        }
-        m->pk_a_allh[w][k] = allh;
-        cur[w] += slot_max[s];
+    /* Slot order inside a wave.  Waves 0..3 (GRU-B waves when S = 4) take their candidate-only slot
+     * first: they start it while the new sample's gather is in flight.  Waves 4..7 take it LAST (slot
+     * index 2): they compute it one sample ahead, in the shadow of GRU-B, and then only run items
+     * [0, bound[2]) in the gather-dependent part of the sample -- no items to skip over. */
+    int slot_at[LPCN_WAVES][LPCN_MAX_SLOTS];
+    for (int w = 0; w < LPCN_WAVES; w++) {
+        int list[LPCN_MAX_SLOTS], n = 0, hslot = -1;
+        for (int k = 0; k < LPCN_MAX_SLOTS; k++) slot_at[w][k] = -1;
+        for (int s = 0; s < NSLOT; s++) if (wave_of[s] == w) list[n++] = s;
+        if (w >= LPCN_WAVES / 2)
+            for (int i = 0; i < n; i++) if (slot_allh[list[i]]) { hslot = list[i]; break; }
+        int k = 0;
+        for (int i = 0; i < n; i++) if (list[i] != hslot) slot_at[w][k++] = list[i];
+        if (hslot >= 0) slot_at[w][LPCN_MAX_SLOTS - 1] = hslot;
     }
     for (int w = 0; w < LPCN_WAVES; w++) {
-        for (int k = fill[w]; k <= LPCN_MAX_SLOTS; k++) m->pk_a_bound[w][k] = cur[w];
-        for (int k = fill[w]; k < LPCN_MAX_SLOTS; k++) m->pk_a_allh[w][k] = 1;
+        int cur = 0;
+        for (int k = 0; k < LPCN_MAX_SLOTS; k++) {
+            const int s = slot_at[w][k], j0 = cur;
+            m->pk_a_bound[w][k] = j0;
+            m->pk_a_allh[w][k] = 1;
+            if (s < 0) continue;
+            int allh = 1;
+            for (int q = 0; q < 8; q++) {
+                const row_group *rg = &g[8 * s + q];
+                if (rg->group * 8 < 2 * LPCN_N_A) allh = 0;
+                for (int r = 0; r < 8; r++) {
+                    int lane = 8 * q + r;
+                    m->pk_a_row[(w * LPCN_MAX_SLOTS + k) * 64 + lane] = rg->group * 8 + r;
+                    for (int j = 0; j < rg->count; j++) {
+                        size_t item = ((size_t)w * nw + (j0 + j)) * 64 + lane;
+                        if (m->is_int8) {      /* int8 block = [out 8][in 4] (dump_lpcnet.py:106): the row's 4 bytes are one dword */
+                            const signed char *blkq = (const signed char *)m->a_w + (size_t)(rg->first_block + j) * 32;
+                            memcpy(&m->pk_a_wq[item], blkq + r * 4, 4);
+                        } else {               /* float block = [in 4][out 8] (dump_lpcnet.py:107) */
+                            const float *blkw = m->a_w + (size_t)(rg->first_block + j) * 32;
+                            for (int c = 0; c < 4; c++) m->pk_a_w[item * 4 + c] = blkw[c * 8 + r];
+                        }
+                        m->pk_a_blk[item] = (uint8_t)(rg->pos[j] >> 2);
+                    }
+                }
+            }
+            m->pk_a_allh[w][k] = allh;
+            cur += slot_max[s];
+        }
+        m->pk_a_bound[w][LPCN_MAX_SLOTS] = cur;
     }
     /* Embedding tables re-ordered to the lane layout: E'[level][slot 0..2][thread 0..511] holds the
      * table entry of the row thread t owns in slot k, so the per-sample gather of one slot is a

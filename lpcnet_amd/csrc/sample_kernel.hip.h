@@ -270,6 +270,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     int b3 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 3]);   // this wave's item count
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
     const bool b_dense = Ap->b_dense != 0;
+    // waves that do not run GRU-B and whose LAST slot holds only candidate rows compute that slot one sample ahead
+    const bool early_wave = __builtin_amdgcn_readfirstlane(((tid0 >> 6) >= S && as_global(Ap->a_allh)[(tid0 >> 6) * 3 + 2] != 0 &&
+                                                            __ballot(row[2] >= 0) != 0ull && b3 > b2) ? 1 : 0) != 0;      // wave-uniform
 
     // ------------------------------------------------------------------ LDS residents -------
     {
@@ -366,6 +369,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     // other waves run ahead into the rows that need no gathered input and pick the new indices
     // up through this flag (LDS operations of one wave complete in order).
     int seq = 0;                                             // samples opened so far (identical in every wave)
+    // Waves that do not run GRU-B (wave >= S) and whose last slot holds only candidate rows compute that
+    // slot for the NEXT sample while GRU-B runs: those rows start from bias + diag*h, which is final
+    // once the gate stage is done, and they make up most of GRU-A's blocks.  (model_pack.c puts the
+    // candidate-only slot of waves 4..7 last, so the rest of the sample simply ends at item bound[2].)
+    bool early_done = false;                                 // wave-uniform
     const uint32_t flag_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::flag);
     auto publish_indices = [&]() {                           // after the sm_idx writes of the same lane
         asm volatile("ds_write_b32 %0, %1" :: "v"(flag_addr), "v"(seq) : "memory");
@@ -459,99 +467,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 }
             };
             LPCN_PROF(5);
-            float acc[S];
+            float acc[S] = {};                               // (initialised for the same reason as ge)
             // state blocks are fetched PF items ahead of their use
             constexpr int PF = 2;
-            HT hq[PF + 1];
+            HT hq[PF + 1] = {};
             auto fetch_h = [&](const int j) {
                 uint32_t pk = offp[j >> 1];
                 LPCN_REMAT_V(pk);                            // keep the unpack inside the sample loop
                 const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
                 hq[j % (PF + 1)] = *(const HT *)(smem + L::hA + off);
             };
-            // start value of row slot k: bias + diag*h (+ gathered input for the update/reset rows),
-            // gather sum in the reference's order ((cond + sig) + pred) + exc (src/nnet.c:431-440,
-            // :487-489).  Candidate rows park the gathered input in sm_inh for the gate stage.  The
-            // value is parked in the row's own sm_pre cell until the row becomes the running one.
-            auto row_init = [&](const int k, const int set, const bool to_acc) {
-                int r = row[k];
-                LPCN_REMAT_V(r);
-                const bool live_row = r >= 0;
-                r = r < 0 ? 0 : r;
-                const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
-                const bool candidate = r >= 2 * NA;
-                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float b = bias + diag * sm_hT[n * S + s];
-                    const float g = ((sm_cond[r * S + s] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
-                    if (candidate && live_row) sm_inh[n * S + s] = g;
-                    float v = candidate ? b : b + g;
-                    if constexpr (I8) v = v * QS;
-                    if (to_acc) acc[s] = v; else if (live_row) sm_pre[r * S + s] = v;
-                }
-            };
-            auto row_swap = [&](const int k_done, const int k_next) {   // finished row out, next row in
-                int r = row[k_done], r2 = row[k_next];
-                LPCN_REMAT_V(r);
-                LPCN_REMAT_V(r2);
-                if (r >= 0) {
-#pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
-                }
-                r2 = r2 < 0 ? 0 : r2;
-#pragma unroll
-                for (int s = 0; s < S; ++s) acc[s] = sm_pre[r2 * S + s];
-            };
-            auto row_store = [&](const int k) {
-                int r = row[k];
-                LPCN_REMAT_V(r);
-                if (r >= 0) {
-#pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
-                }
-            };
-            // Waves whose first slot holds only candidate rows (the big ones) start it from
-            // bias + diag*h alone: they need neither the new sample's indices nor the gathered rows
-            // for that, so they run ahead while wave 0 still finishes the previous sample.  They
-            // poll for the indices at item JG, issue the gathers, and resolve the gather-dependent
-            // start values at item JSTAR (<= their first slot boundary).  The other waves wait for
-            // the indices and resolve everything up front.  jmode is wave-uniform.
-            constexpr int JG = I8 ? 8 : 4, JSTAR = 18;
-            const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR) ? 1 : 0);
-            if (jmode == 0) {
-                wait_indices();
-                load_indices();
-                gather(1, 0);
-                gather(2, 1);
-                gather(0, 2);
-                row_init(1, 0, false);
-                row_init(2, 1, false);
-                row_init(0, 2, true);
-            } else {
-                int r = row[0];
-                r = r < 0 ? 0 : r;
-                const int n = r - 2 * NA;
-                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    acc[s] = bias + diag * sm_hT[n * S + s];
-                    if constexpr (I8) acc[s] = acc[s] * QS;
-                }
-            }
-            LPCN_PROF(10);     // gather issue + (light waves) wait + start values
-#pragma unroll
-            for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
-            LPCN_REMAT_S(b1);
-            LPCN_REMAT_S(b2);
-            LPCN_REMAT_S(b3);
-            auto item = [&](const int j) {
-                if (j == JSTAR) { if (jmode) { row_init(1, 0, false); row_init(2, 1, false); gather(0, 0); } }
-                if (j >= b3) return;                         // wave-uniform: only this wave's own items
-                // wave-uniform slot boundaries (a slot may be empty: b1 == b2, or b1 == 0)
-                if (j == b1) row_swap(0, 1);
-                if (j == b2) row_swap(1, 2);
-                if (j + PF < NW) fetch_h(j + PF);
+            // one item = (this lane's row) x (one 4-wide input block) for all S streams
+            auto mac = [&](const int j) {
                 // one item = (this lane's row) x (one 4-wide input block) for all S streams; per output
                 // the products are added in block order, columns 0..3 (src/vec.h:355-401)
                 if constexpr (I8) {
@@ -587,22 +514,125 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     }
                 }
                 }
+                        };
+            // start value of row slot k: bias + diag*h (+ gathered input for the update/reset rows),
+            // gather sum in the reference's order ((cond + sig) + pred) + exc (src/nnet.c:431-440,
+            // :487-489).  Candidate rows park the gathered input in sm_inh for the gate stage.  The
+            // value is parked in the row's own sm_pre cell until the row becomes the running one.
+            auto row_init = [&](const int k, const int set, const bool to_acc, const bool park = true) {
+                int r = row[k];
+                LPCN_REMAT_V(r);
+                const bool live_row = r >= 0;
+                r = r < 0 ? 0 : r;
+                const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
+                const bool candidate = r >= 2 * NA;
+                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float b = bias + diag * sm_hT[n * S + s];
+                    const float g = ((sm_cond[r * S + s] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
+                    if (candidate && live_row) sm_inh[n * S + s] = g;
+                    float v = candidate ? b : b + g;
+                    if constexpr (I8) v = v * QS;
+                    if (to_acc) acc[s] = v; else if (live_row && park) sm_pre[r * S + s] = v;
+                }
+            };
+            auto row_swap = [&](const int k_done, const int k_next, const bool store_done = true) {   // finished row out, next row in
+                int r = row[k_done], r2 = row[k_next];
+                LPCN_REMAT_V(r);
+                LPCN_REMAT_V(r2);
+                if (r >= 0 && store_done) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
+                }
+                r2 = r2 < 0 ? 0 : r2;
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[s] = sm_pre[r2 * S + s];
+            };
+            auto row_store = [&](const int k) {
+                int r = row[k];
+                LPCN_REMAT_V(r);
+                if (r >= 0) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
+                }
+            };
+            // Waves whose first slot holds only candidate rows (the big ones) start it from
+            // bias + diag*h alone: they need neither the new sample's indices nor the gathered rows
+            // for that, so they run ahead while wave 0 still finishes the previous sample.  They
+            // poll for the indices at item JG, issue the gathers, and resolve the gather-dependent
+            // start values at item JSTAR (<= their first slot boundary).  The other waves wait for
+            // the indices and resolve everything up front.  jmode is wave-uniform.
+            constexpr int JG = I8 ? 8 : 4, JSTAR = 18;
+            // skip2: this wave already finished its last slot for this sample while GRU-B of the previous
+            // sample was running (see P3): its items end at b2 and slot 2 is neither parked nor stored again
+            const bool skip2 = early_done;
+            early_done = false;
+            const int jend = skip2 ? b2 : b3;
+            const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR) ? 1 : 0);
+            if (jmode == 0) {
+                wait_indices();
+                load_indices();
+                gather(1, 0);
+                gather(2, 1);
+                gather(0, 2);
+                row_init(1, 0, false);
+                row_init(2, 1, false, !skip2);               // (candidate rows still need their input part)
+                row_init(0, 2, true);
+            } else {
+                int r = row[0];
+                r = r < 0 ? 0 : r;
+                const int n = r - 2 * NA;
+                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    acc[s] = bias + diag * sm_hT[n * S + s];
+                    if constexpr (I8) acc[s] = acc[s] * QS;
+                }
+            }
+            LPCN_PROF(10);     // gather issue + (light waves) wait + start values
+#pragma unroll
+            for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
+            LPCN_REMAT_S(b1);
+            LPCN_REMAT_S(b2);
+            LPCN_REMAT_S(b3);
+            // All tests below are wave-uniform scalar branches.  A taken branch costs ~35 clk of refetch, so the
+            // common case (an ordinary item) must fall through every one of them: hence the expectations.
+            auto item = [&](const int j) -> bool {           // false: this wave has no more items
+                if (j == JSTAR) { if (jmode) { row_init(1, 0, false); row_init(2, 1, false, !skip2); gather(0, 0); __builtin_amdgcn_s_waitcnt(0xC07F); } }
+                if (__builtin_expect(j >= jend, 0)) return false;
+                if (j + PF < NW) fetch_h(j + PF);
+                // slot boundaries (a slot may be empty: b1 == b2, or b1 == 0)
+                // (the rare blocks drain their own LDS traffic -- s_waitcnt lgkmcnt(0) -- so that the join with the
+                // common path keeps its precise wait counts)
+                if (__builtin_expect(j == b1, 0)) { row_swap(0, 1); __builtin_amdgcn_s_waitcnt(0xC07F); }
+                if (__builtin_expect(j == b2, 0)) { row_swap(1, 2); __builtin_amdgcn_s_waitcnt(0xC07F); }
+                mac(j);
+                return true;
             };
 #pragma unroll
-            for (int j = 0; j < JG && j < NW; ++j) item(j);
+            for (int j = 0; j < JG && j < NW; ++j) item(j);  // (no wave ends before JG: jmode needs b1 >= JSTAR, others just fall through)
             if (jmode) { wait_indices(); load_indices(); gather(1, 0); gather(2, 1); }      // between two fully unrolled halves
-#pragma unroll
-            for (int j = JG; j < NW; ++j) item(j);
+            // straight-line items JG..NW-1 with ONE exit branch (compile-time recursion instead of an unrolled
+            // loop with a break, which the unroller refuses)
+            auto run_items = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j < NW) {
+                    if (!item(j)) return;
+                    self(self, std::integral_constant<int, j + 1>{});
+                }
+            };
+            run_items(run_items, std::integral_constant<int, JG>{});
             LPCN_PROF(9);      // item loop (incl. the mid-phase start values of the heavy waves)
             // close whichever slot is still open; slots that start exactly at NW have no items
             // (b1 <= b2 <= NW; items past a wave's last real item carry zero weights)
-            if (b1 >= b3) {
+            if (b1 >= jend) {
                 row_swap(0, 1);
                 row_swap(1, 2);
-                row_store(2);
-            } else if (b2 >= b3) {
+                if (!skip2) row_store(2);
+            } else if (b2 >= jend) {
                 row_swap(1, 2);
-                row_store(2);
+                if (!skip2) row_store(2);
             } else {
                 row_store(2);
             }
@@ -816,6 +846,34 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                         if constexpr (I8) smem[L::hBq + s * NB + lane] = (unsigned char)quant_s8(hnew);
                     }
                 }
+            } else if (early_wave) {
+                // ---- GRU-A's last slot of the next sample (runs in the shadow of GRU-B): items [b2, b3)
+                {
+                    int r = row[2];
+                    LPCN_REMAT_V(r);
+                    r = r < 0 ? 0 : r;
+                    const int n = r - 2 * NA;
+                    const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        acc[s] = bias + diag * sm_hT[n * S + s];
+                        if constexpr (I8) acc[s] = acc[s] * QS;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
+                auto run_early = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (j < NW) {
+                        if (__builtin_expect(j >= b3, 0)) return;
+                        if (j + PF < NW) fetch_h(j + PF);
+                        if (j >= b2) mac(j);
+                        self(self, std::integral_constant<int, j + 1>{});
+                    }
+                };
+                run_early(run_early, std::integral_constant<int, 0>{});
+                row_store(2);
+                early_done = true;
             }
             __syncthreads();                                                   // B3
             LPCN_PROF(2);
