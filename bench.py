@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per step")
     ap.add_argument("--spw", type=int, default=0, help="streams per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--int8", action="store_true",
+                    help="BASELINE.json config 4: int8 (DOT_PROD) GRU-A/GRU-B weights, bit-exact vs the reference's generic int8 build "
+                         "(default: float32 weights, the configuration the metric is quoted on)")
     a = ap.parse_args()
 
     import torch
@@ -131,7 +134,7 @@ def main():
     dev = torch.device("cuda", local)
 
     n, F = a.streams, a.frames
-    blob = synth.blob_bytes(synth.make_model())
+    blob = synth.blob_bytes(synth.make_model(flavour="int8" if a.int8 else "float"))
     batch = api.LPCNetBatch(n, blob, device=local)
     if a.spw:
         batch.streams_per_workgroup = a.spw
@@ -198,9 +201,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "int8 weights/activations x f32 accumulate (GRU-A/GRU-B), f32 elsewhere" if a.int8 else "f32", "data": "synthetic",
             "config": {"workload": f"{n} concurrent streams per GPU x {F} frames ({F * 160} samples) per step, "
-                                   "fp32 weights, register-resident block-sparse GRU-A, bit-exact (PARITY) arithmetic",
+                                   + ("int8 GRU weights (v_dot4_i32_i8)" if a.int8 else "fp32 weights")
+                                   + ", register-resident block-sparse GRU-A, bit-exact (PARITY) arithmetic",
                        "streams_per_gpu": n, "frames_per_step": F, "streams_per_workgroup": batch.streams_per_workgroup,
                        "sharding": f"{world} x {n} independent streams, no data-path collective"},
             "roofline": {"bound": "valu_fp32", "kernel": "lpcn::sample_kernel",

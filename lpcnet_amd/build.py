@@ -49,7 +49,7 @@ def build(force=False, verbose=True, prof=False):
         subprocess.check_call(cmd)
 
     o = os.path.join(objdir, "engine.o")
-    run([HIPCC] + HIP_FLAGS + (["-DLPCN_ENABLE_PROF=1"] if prof else []) + ["-c", os.path.join(CSRC, "engine.hip"), "-o", o])
+    run([HIPCC] + HIP_FLAGS + (["-DLPCN_ENABLE_PROF=1"] + (["-DLPCN_PROF_MASK=" + os.environ["LPCN_PROF_MASK"]] if "LPCN_PROF_MASK" in os.environ else []) if prof else []) + ["-c", os.path.join(CSRC, "engine.hip"), "-o", o])
     objs.append(o)
     for c in ("api.c", "model_pack.c"):
         o = os.path.join(objdir, c[:-2] + ".o")

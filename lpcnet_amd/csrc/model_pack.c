@@ -162,12 +162,14 @@ static int pack_gru_a(lpcn_model_host *m)
      * first: they start it while the new sample's gather is in flight.  Waves 4..7 take it LAST (slot
      * index 2): they compute it one sample ahead, in the shadow of GRU-B, and then only run items
      * [0, bound[2]) in the gather-dependent part of the sample -- no items to skip over. */
+    /* (int8 blobs: GRU-B is too short to hide a whole slot behind, every wave keeps its candidate slot first) */
+    const int early_from = m->is_int8 ? LPCN_WAVES : LPCN_WAVES / 2;
     int slot_at[LPCN_WAVES][LPCN_MAX_SLOTS];
     for (int w = 0; w < LPCN_WAVES; w++) {
         int list[LPCN_MAX_SLOTS], n = 0, hslot = -1;
         for (int k = 0; k < LPCN_MAX_SLOTS; k++) slot_at[w][k] = -1;
         for (int s = 0; s < NSLOT; s++) if (wave_of[s] == w) list[n++] = s;
-        if (w >= LPCN_WAVES / 2)
+        if (w >= early_from)
             for (int i = 0; i < n; i++) if (slot_allh[list[i]]) { hslot = list[i]; break; }
         int k = 0;
         for (int i = 0; i < n; i++) if (list[i] != hslot) slot_at[w][k++] = list[i];

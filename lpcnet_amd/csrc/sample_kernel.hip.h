@@ -209,7 +209,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     float *const sm_lead = (float *)(smem + L::lead);
     float *const sm_condb = (float *)(smem + L::condb);
     float *const sm_lpc = (float *)(smem + L::lpc);
-    float *const sm_sig = (float *)(smem + L::sig);
     short *const sm_pcm = (short *)(smem + L::pcmbuf);
     const float *const sm_tansig = (const float *)(smem + L::tansig);
     const float *const sm_ulaw = (const float *)(smem + L::ulaw);
@@ -322,12 +321,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         // leader-lane state (lane s of wave 0 leads stream s); kept in LDS between samples
         if (tid < S) {
             const auto *st = &states[stream_of(tid)];
-#pragma unroll
-            for (int j = 0; j < LPCN_LPC_ORDER; ++j) sm_sig[tid * LPCN_LPC_ORDER + j] = st->last_sig[j];
+            sm_idx[tid] = 0;
             sm_lead[tid * 8 + 0] = 0.f;                                       // pred
             sm_lead[tid * 8 + 1] = st->deemph_mem;
             ((int *)sm_lead)[tid * 8 + 2] = st->last_exc;
-            ((int *)sm_lead)[tid * 8 + 3] = 0;                                // ring head
 #pragma unroll
             for (int j = 0; j < 4; ++j) ((uint32_t *)sm_lead)[tid * 8 + 4 + j] = st->rng[j];
         }
@@ -338,21 +335,35 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     //  * wave 0, lane s ("leader" of stream s): LPC prediction and the three mu-law indices of the
     //    embedding gather (src/lpcnet.c:252-254), published through sm_idx + sm_flag;
     //  * wave 1, lane s: the two KISS99 words that become the 8 tree thresholds (src/nnet.c:178-184).
-    auto start_indices = [&](const int ls, const bool live) {
-        int *li = (int *)sm_lead + ls * 8;
-        if (live) {
-            const int head = li[3];
-            float pred = 0.f;
+    // LPC predictor state of wave 0: lane 16*s + j holds sample j of stream s's history (j = 0 newest,
+    // src/lpcnet.c:252-263) and, per frame, LPC coefficient j.
+    // (lrow/tap are recomputed from the thread id and the coefficient re-read from LDS where needed: every
+    // VGPR that stays live across the GRU-A item loop costs the fp32 engine a spill)
+#define LPCN_LROW ((tid0 & 63) >> 4)
+#define LPCN_TAP (tid0 & 15)
+    float hist = (tid0 < 16 * S) ? states[stream_of(LPCN_LROW)].last_sig[LPCN_TAP] : 0.f;
+    auto row_shr1 = [](float v, float fill) {               // value of the previous lane of the 16-lane row; lane 0 gets `fill`
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+    };
+    auto open_sample = [&](const bool live, const float newest, const int exc) {     // wave 0, lanes < 16*S
+        int t_ = tid0;
+        LPCN_REMAT_V(t_);
+        const int lrow = (t_ & 63) >> 4, tap = t_ & 15;
+        // pred = ((0 - s0*a0) - s1*a1) - ... in tap order: lane j is correct from step j on, lane 15 after 16 steps
+        const float prod = hist * sm_lpc[t_];                // sm_lpc is [stream][16] = [lane] for wave 0
+        float r = 0.f;
 #pragma unroll
-            for (int j = 0; j < LPCN_LPC_ORDER; ++j)                              // src/lpcnet.c:252
-                pred = pred - sm_sig[ls * LPCN_LPC_ORDER + ((head + j) & 15)] * sm_lpc[ls * LPCN_LPC_ORDER + j];
-            sm_lead[ls * 8 + 0] = pred;
-            // (sig, pred, exc) mu-law indices packed into one word per stream
-            sm_idx[ls] = lpcn_lin2ulaw(sm_sig[ls * LPCN_LPC_ORDER + head]) | (lpcn_lin2ulaw(pred) << 8) | (li[2] << 16);
-        } else {
-            sm_idx[ls] = 0;
+        for (int k = 0; k < LPCN_LPC_ORDER; ++k) r = row_shr1(r, 0.f) - prod;
+        // mu-law index of the newest sample (tap 0) and of the prediction (tap 15) in one pass
+        const int u = lpcn_lin2ulaw(tap == 15 ? r : newest);
+        unsigned char *ib = smem + L::idx + lrow * 4;       // (sig, pred, exc) indices packed into one word per stream
+        if (live) {
+            if (tap == 15) { sm_lead[lrow * 8 + 0] = r; ib[1] = (unsigned char)u; }
+            if (tap == 0) { ib[0] = (unsigned char)u; ib[2] = (unsigned char)exc; }
+        } else if (tap == 0) {
+            sm_idx[lrow] = 0;
         }
-        sm_idx[S + ls] = live ? 1 : 0;
+        if (tap == 0) sm_idx[S + lrow] = live ? 1 : 0;
     };
     auto draw_thresholds = [&](const int ls) {
         int *li = (int *)sm_lead + ls * 8;
@@ -392,7 +403,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     unsigned long long *const prof = Ap->prof;
     unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     const bool profiling = prof != nullptr && blockIdx.x == 0;      // wave-uniform: the counters stay in SGPRs
-#define LPCN_PROF(slot) do { if (profiling) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[slot] += now_ - tprev; tprev = now_; } } while (0)
+#ifndef LPCN_PROF_MASK
+#define LPCN_PROF_MASK 0x7FF        // which of the 12 slots are compiled in (every live counter costs two SGPRs)
+#endif
+#define LPCN_PROF(slot) do { if (((LPCN_PROF_MASK >> (slot)) & 1) && profiling) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[slot] += now_ - tprev; tprev = now_; } } while (0)
 #else
 #define LPCN_PROF(slot) do { } while (0)
 #endif
@@ -410,21 +424,21 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             if (tid < S * RB) sm_condb[tid] = cb[((size_t)stream_of(tid / RB) * nf + f) * RB + tid % RB];
             if (tid < S * LPCN_LPC_ORDER)
                 sm_lpc[tid] = lp[((size_t)stream_of(tid / LPCN_LPC_ORDER) * nf + f) * LPCN_LPC_ORDER + tid % LPCN_LPC_ORDER];
-            if ((tid & 63) < S && tid < 128) {                    // lanes 0..S-1 of wave 0 (leaders) and wave 1 (thresholds)
-                const int lstream = stream_of(tid & 63);
+            if (tid < 16 * S || (tid >= 64 && tid < 64 + S)) {    // wave 0: predictor lanes; wave 1: threshold lanes
+                const int lstream = stream_of(tid < 64 ? LPCN_LROW : tid - 64);
                 const int fc_ref = Ap->fc_base ? as_global(Ap->fc_base)[lstream] : states[lstream].frame_count;
                 int fc = Ap->fc_advance ? fc_ref + f + 1 : fc_ref;
                 if (fc > 1000) fc = 1000;
                 live = fc > LPCN_FEATURES_DELAY;                 // src/lpcnet.c:239-243
-                if (preload > 0 && tid < S) {                     // teacher forcing reads the caller's samples
-                    const auto *pin = as_global(Ap->pcm) + (size_t)lstream * (size_t)Ap->pcm_stride + (size_t)f * LPCN_FRAME_SIZE;
-                    for (int i = 0; i < preload; ++i) sm_pcm[tid * LPCN_FRAME_SIZE + i] = pin[i];
-                }
+            }
+            if (preload > 0 && tid < S) {                         // teacher forcing reads the caller's samples
+                const auto *pin = as_global(Ap->pcm) + (size_t)stream_of(tid) * (size_t)Ap->pcm_stride + (size_t)f * LPCN_FRAME_SIZE;
+                for (int i = 0; i < preload; ++i) sm_pcm[tid * LPCN_FRAME_SIZE + i] = pin[i];
             }
         }
         __syncthreads();        // sm_lpc visible to the leaders
         ++seq;
-        if (tid0 < S) { start_indices(tid0, live); publish_indices(); }
+        if (tid0 < 16 * S) { open_sample(live, hist, ((const int *)sm_lead)[LPCN_LROW * 8 + 2]); publish_indices(); }
         if (tid0 >= 64 && tid0 < 64 + S && live) draw_thresholds(tid0 - 64);
         __syncthreads();
         int live_mask = 0;                                   // bit s: stream s produces samples in this frame
@@ -903,11 +917,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             // sample) work here; everybody else is already in the next sample's GRU-A.
             const bool more = smp + 1 < frame_len;
             if (more) ++seq;
-            if (tid < S) {
+            if (tid < 16 * S) {
+                const int lrow = (tid & 63) >> 4, tap = tid & 15;
                 float pcm = 0.f, deemph = 0.f;
                 int exc = 0;
-                if (live) {
-                    const unsigned long long *mk = sm_mask + tid * 8;
+                if (live) {                                  // (all 16 lanes of a stream's row do the same walk)
+                    const unsigned long long *mk = sm_mask + lrow * 8;
                     const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
                     const unsigned long long m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
                     int val = 0;
@@ -923,38 +938,39 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                         val = (val << 1) | (int)((mw >> (2 * (i & 31))) & 1ull);
                     }
                     exc = val;
-                    int *li = (int *)sm_lead + tid * 8;
-                    const float pred = sm_lead[tid * 8 + 0];
-                    deemph = sm_lead[tid * 8 + 1];
-                    int head = li[3];
+                    const float pred = sm_lead[lrow * 8 + 0];
+                    deemph = sm_lead[lrow * 8 + 1];
                     if (smp < preload) {                                        // src/lpcnet.c:256-258
-                        const float x = (float)sm_pcm[tid * LPCN_FRAME_SIZE + smp];
+                        const float x = (float)sm_pcm[lrow * LPCN_FRAME_SIZE + smp];
                         exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
                         pcm = x - 0.85f * deemph;
                     } else {
                         pcm = pred + sm_ulaw[exc];                              // src/lpcnet.c:260
                     }
-                    head = (head + 15) & 15;                                    // src/lpcnet.c:262-263
-                    sm_sig[tid * LPCN_LPC_ORDER + head] = pcm;
-                    li[3] = head;
-                    li[2] = exc;
                 }
+                {                                            // history shifts by one, the new sample enters at tap 0 (src/lpcnet.c:262-263)
+                    const float shifted = row_shr1(hist, pcm);
+                    hist = live ? shifted : hist;
+                }
+                if (tap == 0 && live) ((int *)sm_lead)[lrow * 8 + 2] = exc;
                 if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live) {
                     float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
                     d[1] = (float)(sm_idx[0] & 0xFF); d[2] = (float)((sm_idx[0] >> 8) & 0xFF);
                 }
                 // the next sample's indices first: the other waves are waiting for them
-                if (more) { start_indices(tid, live); publish_indices(); }
-                if (live) {
-                    if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
-                        float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
-                        d[0] = (float)exc; d[3] = pcm + 0.85f * deemph; d[4] = sm_lead[tid * 8 + 0];
+                if (more) { open_sample(live, pcm, exc); publish_indices(); }
+                if (tap == 0) {
+                    if (live) {
+                        if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
+                            float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
+                            d[0] = (float)exc; d[3] = pcm + 0.85f * deemph; d[4] = pcm - sm_ulaw[exc];
+                        }
+                        pcm = pcm + 0.85f * deemph;
+                        sm_lead[lrow * 8 + 1] = pcm;                            // de-emphasis memory
+                        if (smp >= preload) sm_pcm[lrow * LPCN_FRAME_SIZE + smp] = (short)lpcn_round_pcm(pcm);
+                    } else {
+                        sm_pcm[lrow * LPCN_FRAME_SIZE + smp] = 0;
                     }
-                    pcm = pcm + 0.85f * deemph;
-                    sm_lead[tid * 8 + 1] = pcm;                                 // de-emphasis memory
-                    if (smp >= preload) sm_pcm[tid * LPCN_FRAME_SIZE + smp] = (short)lpcn_round_pcm(pcm);
-                } else {
-                    sm_pcm[tid * LPCN_FRAME_SIZE + smp] = 0;
                 }
             }
             if (more && tid >= 64 && tid < 64 + S && live) draw_thresholds(tid - 64);
@@ -998,15 +1014,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         }
         for (int i = tid; i < S * NB; i += LPCN_WG_THREADS)
             if (i / NB < n_valid) states[s0 + i / NB].gru_b[i % NB] = sm_hB[i];
+        if (tid < 16 * S && LPCN_LROW < n_valid) states[s0 + LPCN_LROW].last_sig[LPCN_TAP] = hist;
         if (tid < n_valid) {
             auto *st = &states[s0 + tid];
             const int *li = (const int *)sm_lead + tid * 8;
-            const int head = li[3];
 #pragma unroll
-            for (int j = 0; j < LPCN_LPC_ORDER; ++j) {
-                st->last_sig[j] = sm_sig[tid * LPCN_LPC_ORDER + ((head + j) & 15)];
-                st->lpc[j] = sm_lpc[tid * LPCN_LPC_ORDER + j];
-            }
+            for (int j = 0; j < LPCN_LPC_ORDER; ++j) st->lpc[j] = sm_lpc[tid * LPCN_LPC_ORDER + j];
             st->deemph_mem = sm_lead[tid * 8 + 1];
             st->last_exc = li[2];
 #pragma unroll

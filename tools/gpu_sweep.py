@@ -33,8 +33,8 @@ def main():
         print(f"n={n:5d} S={S} exact={ok} sample_kernel={ms_s:8.2f} ms frame_kernels={ms_f:6.2f} ms wall={wall*1e3:8.1f} ms "
               f"-> {live/(ms_s*1e-3)/1e6:8.2f} M samples/s (kernel), us/step={ms_s*1e3/((T-2)*160):6.2f} ", flush=True)
         if prof.any():
-            print("   per-wave clk/step [B1wait P2 P3tail P4 P5 | gather close fcpre gruB items start]:")
-            for w in range(8): print("   wave", w, " ".join("%6.0f" % x for x in prof[w*12:w*12+11]), flush=True)
+            print("   per-wave clk/step [B1wait P2 P3tail P4 P5 | gather close fcpre gruB items start P5a]:")
+            for w in range(8): print("   wave", w, " ".join("%6.0f" % x for x in prof[w*12:w*12+12]), flush=True)
         b.close()
 
 if __name__ == "__main__":
