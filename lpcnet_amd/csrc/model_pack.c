@@ -93,54 +93,66 @@ static int pack_gru_a(lpcn_model_host *m)
     }
     qsort(g, NG, sizeof(g[0]), cmp_group_desc);
 
-    /* Slot -> wave assignment with a small cost model of the kernel (unit: items).
-     *  - candidate-only ("all-h") slots go first, one per wave: their rows start from bias +
-     *    diag*h alone, so such a wave runs them while the previous sample's leader work and the
-     *    embedding gather of the new sample are still in flight (~G items of time);
-     *  - waves without one idle until the gather has landed: both kinds pay max(first slot, G);
-     *  - every slot costs ~2 items of begin/end work;
-     *  - remaining slots: longest-processing-time on the wave cost;
-     *  - finally waves are renumbered by item count: the four with the fewest items become waves
-     *    0..3 (wave 0 leads the streams, wave 1 draws the random thresholds, waves 0..S-1 run
-     *    GRU-B: their extra duties fall into the time the others spend on items) and each shares
-     *    a SIMD with one of the busiest (waves w and w+4 of a workgroup land on the same SIMD). */
+    /* Slot -> wave assignment with a small cost model of the sample kernel (unit: items).
+     * Roles (fp32 blobs; int8 blobs have no "early" waves because their GRU-B is too short to hide a slot):
+     *  - "early" waves (ids 4..7): take the largest candidate-only ("all-h") slots.  That slot is computed
+     *    one sample ahead in the shadow of GRU-B, so in the gather-dependent part of the sample it is free;
+     *  - "first" waves: a remaining all-h slot runs first, while the previous sample's leader work and the
+     *    embedding gather of the new sample are in flight (~G items of time): they pay max(slot, G) and
+     *    take only one more slot;
+     *  - all other waves idle for G until the gather has landed.
+     * Every further slot costs its items + ~2 for begin/end work; they are dealt longest-first to the
+     * cheapest wave that still has a slot position and register room (items per lane = VGPRs).
+     * Finally the waves are renumbered: early waves -> 4..7; of the rest the one with the fewest items
+     * becomes wave 0 (it leads the streams), the next wave 1 (it draws the random thresholds). */
     const int G = m->is_int8 ? 30 : 20;
+    const int n_early_max = m->is_int8 ? 0 : LPCN_WAVES / 2;
     int slot_max[NSLOT], slot_allh[NSLOT], wave_of[NSLOT], nslots[LPCN_WAVES] = {0};
-    int items[LPCN_WAVES] = {0}, cost[LPCN_WAVES] = {0};
+    int items[LPCN_WAVES] = {0}, cost[LPCN_WAVES] = {0}, early[LPCN_WAVES] = {0}, maxslots[LPCN_WAVES];
     for (int s = 0; s < NSLOT; s++) {
         slot_max[s] = g[8 * s].count;
         slot_allh[s] = 1;
         wave_of[s] = -1;
         for (int q = 0; q < 8; q++) if (g[8 * s + q].group * 8 < 2 * LPCN_N_A) slot_allh[s] = 0;
     }
-    for (int s = 0; s < NSLOT; s++) {               /* pass 1: all-h slots onto empty waves */
-        if (!slot_allh[s]) continue;
-        int best = -1;
-        for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) { best = w; break; }
-        if (best < 0) continue;
-        wave_of[s] = best; nslots[best] = 1; items[best] = slot_max[s];
-        cost[best] = (slot_max[s] > G ? slot_max[s] : G) + 2;
+    for (int w = 0; w < LPCN_WAVES; w++) { cost[w] = G; maxslots[w] = LPCN_MAX_SLOTS; }
+    {
+        int n_early = 0;
+        for (int s = 0; s < NSLOT; s++) {           /* pass 1: all-h slots onto empty waves (slots are in descending order) */
+            if (!slot_allh[s]) continue;
+            int best = -1;
+            for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) { best = w; break; }
+            if (best < 0) continue;
+            wave_of[s] = best; nslots[best] = 1; items[best] = slot_max[s];
+            if (n_early < n_early_max) { early[best] = 1; n_early++; cost[best] = G + 2; }
+            else {
+                /* a "first" wave keeps two gather register sets in flight while its items run: one more slot only */
+                cost[best] = (slot_max[s] > G ? slot_max[s] : G) + 2;
+                maxslots[best] = 2;
+            }
+        }
     }
-    for (int w = 0; w < LPCN_WAVES; w++) if (nslots[w] == 0) cost[w] = G;
     int cap = 0;                                    /* items per wave = VGPRs: do not exceed the unavoidable maximum */
     for (int s = 0; s < NSLOT; s++) cap += slot_max[s];
     cap = (cap + LPCN_WAVES - 1) / LPCN_WAVES + 2;
     if (cap < slot_max[0]) cap = slot_max[0];
-    for (int s = 0; s < NSLOT; s++) {               /* pass 2: LPT (slots are in descending order) */
+    for (int s = 0; s < NSLOT; s++) {               /* pass 2: longest-processing-time for the rest */
         if (wave_of[s] >= 0) continue;
         int best = -1;
         for (int pass = 0; pass < 2 && best < 0; pass++)
             for (int w = 0; w < LPCN_WAVES; w++)
-                if (nslots[w] < LPCN_MAX_SLOTS && (pass || items[w] + slot_max[s] <= cap) && (best < 0 || cost[w] < cost[best])) best = w;
+                if (nslots[w] < maxslots[w] && (pass || items[w] + slot_max[s] <= cap) && (best < 0 || cost[w] < cost[best])) best = w;
         wave_of[s] = best; nslots[best]++; items[best] += slot_max[s]; cost[best] += slot_max[s] + 2;
     }
-    {   /* pass 3: renumber waves: lightest -> wave 0, each paired with a heavy one on its SIMD */
-        int order[LPCN_WAVES], newid[LPCN_WAVES];
+    {   /* pass 3: renumber */
+        int order[LPCN_WAVES], newid[LPCN_WAVES], lo = 0, hi = LPCN_WAVES - 1;
         for (int w = 0; w < LPCN_WAVES; w++) order[w] = w;
-        for (int i = 0; i < LPCN_WAVES; i++)
-            for (int j = i + 1; j < LPCN_WAVES; j++)
-                if (items[order[j]] > items[order[i]]) { int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
-        for (int i = 0; i < LPCN_WAVES / 2; i++) { newid[order[LPCN_WAVES - 1 - i]] = i; newid[order[i]] = i + 4; }
+        for (int i = 0; i < LPCN_WAVES; i++)       /* early waves last, otherwise ascending item count */
+            for (int j = i + 1; j < LPCN_WAVES; j++) {
+                const int a = order[i], c = order[j];
+                if (early[c] < early[a] || (early[c] == early[a] && items[c] < items[a])) { order[i] = c; order[j] = a; }
+            }
+        for (int i = 0; i < LPCN_WAVES; i++) { if (early[order[i]]) newid[order[i]] = hi--; else newid[order[i]] = lo++; }
         int items2[LPCN_WAVES];
         for (int w = 0; w < LPCN_WAVES; w++) items2[newid[w]] = items[w];
         for (int w = 0; w < LPCN_WAVES; w++) items[w] = items2[w];

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     int b3 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 3]);   // this wave's item count
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
     const bool b_dense = Ap->b_dense != 0;
+    const bool has2 = __builtin_amdgcn_readfirstlane(__ballot(row[2] >= 0) != 0ull ? 1 : 0) != 0;     // this wave owns a third slot
     // waves that do not run GRU-B and whose LAST slot holds only candidate rows compute that slot one sample ahead
     const bool early_wave = __builtin_amdgcn_readfirstlane(((tid0 >> 6) >= S && as_global(Ap->a_allh)[(tid0 >> 6) * 3 + 2] != 0 &&
                                                             __ballot(row[2] >= 0) != 0ull && b3 > b2) ? 1 : 0) != 0;      // wave-uniform
@@ -613,7 +614,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             // All tests below are wave-uniform scalar branches.  A taken branch costs ~35 clk of refetch, so the
             // common case (an ordinary item) must fall through every one of them: hence the expectations.
             auto item = [&](const int j) -> bool {           // false: this wave has no more items
-                if (j == JSTAR) { if (jmode) { row_init(1, 0, false); row_init(2, 1, false, !skip2); gather(0, 0); __builtin_amdgcn_s_waitcnt(0xC07F); } }
+                if (j == JSTAR) {
+                    if (jmode) {
+                        row_init(1, 0, false);
+                        if (has2) { row_init(2, 1, false, !skip2); gather(0, 0); }     // (two-slot waves already hold slot 0's rows in set 1)
+                        __builtin_amdgcn_s_waitcnt(0xC07F);
+                    }
+                }
                 if (__builtin_expect(j >= jend, 0)) return false;
                 if (j + PF < NW) fetch_h(j + PF);
                 // slot boundaries (a slot may be empty: b1 == b2, or b1 == 0)
@@ -626,7 +633,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             };
 #pragma unroll
             for (int j = 0; j < JG && j < NW; ++j) item(j);  // (no wave ends before JG: jmode needs b1 >= JSTAR, others just fall through)
-            if (jmode) { wait_indices(); load_indices(); gather(1, 0); gather(2, 1); }      // between two fully unrolled halves
+            if (jmode) {                                     // between two fully unrolled halves
+                wait_indices();
+                load_indices();
+                gather(1, 0);
+                if (has2) gather(2, 1); else gather(0, 1);   // a third slot's rows are fetched when set 0 is free again (JSTAR)
+            }
             // straight-line items JG..NW-1 with ONE exit branch (compile-time recursion instead of an unrolled
             // loop with a break, which the unroller refuses)
             auto run_items = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
@@ -655,9 +667,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
                     const int n = r - 2 * NA;
+                    if (has2) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s)
-                        sm_inh[n * S + s] = ((sm_cond[r * S + s] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
+                        for (int s = 0; s < S; ++s)
+                            sm_inh[n * S + s] = ((sm_cond[r * S + s] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+                            sm_inh[n * S + s] = ((sm_cond[r * S + s] + ge[1][0][s]) + ge[1][1][s]) + ge[1][2][s];
+                    }
                 }
             }
             LPCN_PROF(6);      // slots: begin + items + end
