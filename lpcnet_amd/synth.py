@@ -129,7 +129,7 @@ def _sparse_blocks(A, q):
 
 
 def make_model(seed=1234, flavour="float", shaped=True, densities=(0.05, 0.05, 0.2),
-               lpc_gamma=1.0):
+               lpc_gamma=1.0, grub_density=1.0):
     """Build the synthetic model.  The *same* seed gives the same network in both flavours
     (weights are snapped to k/128); only the qweight element type / blocking differs."""
     assert flavour in ("float", "int8")
@@ -155,7 +155,14 @@ def make_model(seed=1234, flavour="float", shaped=True, densities=(0.05, 0.05, 0
 
     # ---- GRU-B (input part 384->48 block-sparse at density 1, 128->48 dense, recurrent 16->48)
     Wb_in = normal((N_A + COND, 3 * N_B), 0.07)
-    Wb_a, Qb_a = _quantize_matrix(Wb_in[:N_A])
+    Wb_gru = Wb_in[:N_A]
+    if grub_density < 1.0:
+        # block-sparse GRU-B input matrix (lpcnet.py --grub-density-split): keep the strongest 4x8 blocks
+        L = Wb_gru.reshape(N_A // 4, 4, 3 * N_B // 8, 8)
+        energy = (L * L).sum(axis=3).sum(axis=1)
+        thresh = np.sort(energy.reshape(-1))[int(round(energy.size * (1 - grub_density)))]
+        Wb_gru = Wb_gru * np.repeat(np.repeat((energy >= thresh).astype(f32), 4, axis=0), 8, axis=1)
+    Wb_a, Qb_a = _quantize_matrix(Wb_gru)
     m.add("gru_b_dense_feature_weights", Wb_in[N_A:], WEIGHT_TYPE_FLOAT)
     m.add("gru_b_dense_feature_bias", np.zeros(3 * N_B, f32), WEIGHT_TYPE_FLOAT)
     W0, W, idx = _sparse_blocks(Wb_a, Qb_a)

@@ -322,3 +322,29 @@ def test_int8_streaming_state_roundtrip(blob_i8, hip_lib):
     parts = np.concatenate([b.synthesize(feats[:, :5]), b.synthesize(feats[:, 5:6]), b.synthesize(feats[:, 6:])], axis=1)
     assert np.array_equal(whole, parts)
     b.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(densities=(0.02, 0.02, 0.1)),                                  # sparse GRU-A: smallest item-count variant
+    dict(densities=(0.07, 0.07, 0.25)),                                 # denser GRU-A: a larger register-resident variant
+    dict(grub_density=0.3),                                             # block-sparse GRU-B input matrix (indexed path)
+    dict(flavour="int8", densities=(0.07, 0.07, 0.25), grub_density=0.4),
+    dict(shaped=False, densities=(0.04, 0.06, 0.15), grub_density=0.6, seed=77),
+], ids=["sparseA", "denseA", "sparseB", "int8-denseA-sparseB", "unshaped"])
+def test_other_model_shapes_match_oracle(kw, hip_lib):
+    """the slot packing, the item-count variants and the GRU-B paths depend on the model: other sparsity patterns"""
+    blob = synth.blob_bytes(synth.make_model(**kw))
+    rc, info = api.check_model(blob)
+    assert rc == 0 and info[5] == 0
+    n, T = 5, 7
+    feats = feats_for(range(2300, 2300 + n), T)
+    want, states = oracle_run(blob, feats)
+    for S in (1, 4):
+        b = api.LPCNetBatch(n, blob)
+        b.streams_per_workgroup = S
+        got = b.synthesize(feats)
+        assert np.array_equal(got, want), (kw, S)
+        st = b.get_state(n - 1)
+        _, _, ga, gb = states[n - 1].nnet_state()
+        assert np.array_equal(np.array(st.gru_a, np.float32), ga) and np.array_equal(np.array(st.gru_b, np.float32), gb)
+        b.close()
