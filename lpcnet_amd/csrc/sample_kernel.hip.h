@@ -269,7 +269,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     int b3 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 3]);   // this wave's item count
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
     const bool b_dense = Ap->b_dense != 0;
-    const bool has2 = __builtin_amdgcn_readfirstlane(__ballot(row[2] >= 0) != 0ull ? 1 : 0) != 0;     // this wave owns a third slot
+    // bit k: this wave owns rows in slot k (wave-uniform)
+    const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row[1] >= 0) != 0ull ? 2 : 0) |
+                                                        (__ballot(row[2] >= 0) != 0ull ? 4 : 0));
+    const bool has2 = (has_slot & 4) != 0;
     // waves that do not run GRU-B and whose LAST slot holds only candidate rows compute that slot one sample ahead
     const bool early_wave = __builtin_amdgcn_readfirstlane(((tid0 >> 6) >= S && as_global(Ap->a_allh)[(tid0 >> 6) * 3 + 2] != 0 &&
                                                             __ballot(row[2] >= 0) != 0ull && b3 > b2) ? 1 : 0) != 0;      // wave-uniform
@@ -473,6 +476,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 }
             };
             auto gather = [&](const int k, const int set) {
+                if (!((has_slot >> k) & 1)) return;          // this wave owns no rows in slot k: nothing to fetch (ge stays 0)
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     // the mu-law indices are workgroup-uniform: scalar row base + lane offset
