@@ -10,8 +10,12 @@ step     = one pass of the hot path (frame network + LPC + 160-sample loop per f
            weak scaling: every GPU gets its own 1024 streams = config 3 at N = 8).
 value    = whole-job 16 kHz samples per second (sum over GPUs / max-over-ranks time);
            concurrent real-time streams = value / 16000.
-roofline = the sample kernel (dominant, >98 % of the step) priced at the algorithmic
-           129 698 flop per output sample against the fp32 vector peak; launch time is
+roofline = the sample kernel (dominant, >98 % of the step).  SURVEY.md §8(d): not MFMA; the primary bound
+           is on-chip operand bandwidth, so `achieved` = algorithmic operand bytes per stream-sample
+           (286 704 B fp32 / 96 432 B int8: every weight and table entry once per sample) x samples per
+           launch / launch time, against the 150 TB/s LDS peak; the fp32-VALU flop fraction (129 698 flop
+           per sample vs 157.3 TFLOP/s) and the HBM-side fraction (13 857 B per sample vs 8 TB/s) ride
+           along; `traffic` = HBM bytes per launch from the rocprofv3 PMC counters.  Launch time is
            measured live with HIP events on the stream the kernel runs on.
 cpu_baseline = the reference's own AVX2 float build (oracle/_ref, `kind: reference`) or, if that
            prebuilt library is absent, the plain-C oracle (`kind: port`), timed here on the host
@@ -34,6 +38,7 @@ FRAMES_PER_STEP = 25                    # 0.25 s of audio per stream and step
 FLOP_PER_SAMPLE = 129698                # 64 849 MAC
 HBM_BYTES_PER_SAMPLE = 13857            # embedding gather 13 824 + PCM 2 + frame I/O 31
 LDS_OPERAND_BYTES_PER_SAMPLE = 286704   # every fp32 operand once per stream-sample
+LDS_OPERAND_BYTES_PER_SAMPLE_I8 = 96432 # int8 GRU-A 59 544 + int8 GRU-B 21 912 + fp32 tree 1 152 + embedding rows 13 824
 PEAK_FP32_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector peak
 PEAK_HBM_GBS = 8000.0
 PEAK_LDS_TBS = 150.0
@@ -187,8 +192,10 @@ def main():
         launch_flop = samples_per_step * FLOP_PER_SAMPLE
         achieved_tflops = launch_flop / (ms_sample * 1e-3) / 1e12
         kernel_rate = samples_per_step / (ms_sample * 1e-3)
+        op_bytes = LDS_OPERAND_BYTES_PER_SAMPLE_I8 if a.int8 else LDS_OPERAND_BYTES_PER_SAMPLE
+        op_gbs = kernel_rate * op_bytes / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_int8.json" if a.int8 else "r01_hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -207,14 +214,15 @@ def main():
                                    + ", register-resident block-sparse GRU-A, bit-exact (PARITY) arithmetic",
                        "streams_per_gpu": n, "frames_per_step": F, "streams_per_workgroup": batch.streams_per_workgroup,
                        "sharding": f"{world} x {n} independent streams, no data-path collective"},
-            "roofline": {"bound": "valu_fp32", "kernel": "lpcn::sample_kernel",
-                         "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "lds_operand_bandwidth", "kernel": "lpcn::sample_kernel",
+                         "achieved": op_gbs, "peak": PEAK_LDS_TBS * 1e3, "unit": "GB/s",
+                         "frac": op_gbs / (PEAK_LDS_TBS * 1e3), "traffic": traffic,
                          "launch_ms": ms_sample, "frame_kernels_ms": ms_frame,
-                         "flop_per_sample": FLOP_PER_SAMPLE,
-                         "lds_operand": {"achieved_TBs": kernel_rate * LDS_OPERAND_BYTES_PER_SAMPLE / 1e12,
-                                         "peak_TBs": PEAK_LDS_TBS,
-                                         "frac": kernel_rate * LDS_OPERAND_BYTES_PER_SAMPLE / 1e12 / PEAK_LDS_TBS},
+                         "operand_bytes_per_sample": op_bytes,
+                         "note": "algorithmic operand bytes (each weight/table entry once per stream-sample); the engine keeps "
+                                 "GRU-A weights in VGPRs and shares every LDS read among the workgroup's streams, so realised LDS bytes are lower",
+                         "valu_fp32": {"achieved_TFLOPs": achieved_tflops, "peak_TFLOPs": PEAK_FP32_TFLOPS,
+                                       "frac": achieved_tflops / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE},
                          "hbm": {"achieved_GBs": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS}},
         }
