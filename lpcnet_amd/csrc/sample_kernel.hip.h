@@ -477,12 +477,21 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             };
             auto gather = [&](const int k, const int set) {
                 if (!((has_slot >> k) & 1)) return;          // this wave owns no rows in slot k: nothing to fetch (ge stays 0)
+                uint32_t toff = (uint32_t)tid0 * 4u;
+                LPCN_REMAT_V(toff);                          // keep the lane offset a 32-bit VGPR (no hoisted 64-bit per-lane table bases)
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     // the mu-law indices are workgroup-uniform: scalar row base + lane offset
-                    ge[set][0][s] = (emb_sig + (size_t)((gi[s] & 0xFF) * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS)[tid0];
-                    ge[set][1][s] = (emb_pred + (size_t)(((gi[s] >> 8) & 0xFF) * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS)[tid0];
-                    ge[set][2][s] = (emb_exc + (size_t)((gi[s] >> 16) * LPCN_MAX_SLOTS + k) * LPCN_WG_THREADS)[tid0];
+                    // scalar row base (table + level*6 KB + slot*2 KB) + 32-bit lane offset: one SGPR-pair add per load
+                    const uint32_t i0 = (uint32_t)(gi[s] & 0xFF), i1 = (uint32_t)((gi[s] >> 8) & 0xFF), i2 = (uint32_t)(gi[s] >> 16) & 0xFFu;
+                    const LPCN_GLOBAL char *r0 = (const LPCN_GLOBAL char *)emb_sig + (size_t)((i0 * LPCN_MAX_SLOTS + k) * (LPCN_WG_THREADS * 4u));
+                    const LPCN_GLOBAL char *r1 = (const LPCN_GLOBAL char *)emb_pred + (size_t)((i1 * LPCN_MAX_SLOTS + k) * (LPCN_WG_THREADS * 4u));
+                    const LPCN_GLOBAL char *r2 = (const LPCN_GLOBAL char *)emb_exc + (size_t)((i2 * LPCN_MAX_SLOTS + k) * (LPCN_WG_THREADS * 4u));
+                    // (opaque scalar pointers: otherwise LLVM re-associates to per-lane 64-bit VGPR addresses)
+                    asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2));
+                    ge[set][0][s] = *(const LPCN_GLOBAL float *)(r0 + toff);
+                    ge[set][1][s] = *(const LPCN_GLOBAL float *)(r1 + toff);
+                    ge[set][2][s] = *(const LPCN_GLOBAL float *)(r2 + toff);
                 }
             };
             LPCN_PROF(5);
