@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the round's measurement evidence on a GPU box (run through gpurun from the repo root):
+#   bench JSON lines (fp32 + int8), rocprofv3 kernel stats, HBM traffic from PMC counters (separate passes).
+# Everything lands in gpurun_out/prof/; tools/profile_summarize.py turns it into profiles/.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+OUT=gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
+timeout 300 python bench.py --int8 --no-cpu-baseline > $OUT/bench_i8.json 2> $OUT/bench_i8.err
+for fl in f32 i8; do
+  flag=""; [ $fl = i8 ] && flag="--int8"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
+done
+find $OUT -name "*.csv" | head -40
