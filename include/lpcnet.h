@@ -60,6 +60,19 @@ LPCNET_EXPORT void lpcnet_synthesize(LPCNetState *st, const float *features, sho
  * Unlike the reference the blob is copied to the device and need not outlive the state. */
 LPCNET_EXPORT int lpcnet_load_model(LPCNetState *st, const unsigned char *data, int len);
 
+/* ---- internal entry points of the reference (src/lpcnet_private.h:125-132).  src/lpcnet_plc.c links to them:
+ * exporting them with the same names and meaning lets the unmodified PLC drive this engine.
+ * LPCNetState holds the frame products between run_frame_network and lpcnet_synthesize_tail_impl, as in the
+ * reference, and may be copied by value (snapshot / rollback, src/lpcnet_plc.c:216-231). */
+LPCNET_EXPORT void lpcnet_reset_signal(LPCNetState *lpcnet);                                                  /* src/lpcnet.c:226-233 */
+LPCNET_EXPORT void run_frame_network(LPCNetState *lpcnet, float *gru_a_condition, float *gru_b_condition,
+                                     float *lpc, const float *features);                                      /* src/lpcnet.c:82-120 */
+LPCNET_EXPORT void run_frame_network_deferred(LPCNetState *lpcnet, const float *features);                    /* src/lpcnet.c:122-132 */
+LPCNET_EXPORT void run_frame_network_flush(LPCNetState *lpcnet);                                              /* src/lpcnet.c:134-144 */
+LPCNET_EXPORT void lpcnet_synthesize_tail_impl(LPCNetState *lpcnet, short *output, int N, int preload);      /* src/lpcnet.c:235-271 */
+LPCNET_EXPORT void lpcnet_synthesize_impl(LPCNetState *lpcnet, const float *features, short *output, int N,
+                                          int preload);                                                       /* src/lpcnet.c:273-277 */
+
 /* ---- additions (not in the reference) ------------------------------------------------------ */
 /* message of the last failure on the calling thread ("" if none) */
 LPCNET_EXPORT const char *lpcnet_hip_last_error(void);

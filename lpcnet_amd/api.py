@@ -51,6 +51,19 @@ def load_library():
     L.lpcnet_synthesize.argtypes = [vp, _f32p, _i16p, C.c_int]
     L.lpcnet_synthesize.restype = None
     L.lpcnet_load_model.argtypes = [vp, C.c_char_p, C.c_int]
+    # the reference's internal entry points (src/lpcnet_private.h:125-132)
+    L.lpcnet_reset_signal.argtypes = [vp]
+    L.lpcnet_reset_signal.restype = None
+    L.run_frame_network.argtypes = [vp, _f32p, _f32p, _f32p, _f32p]
+    L.run_frame_network.restype = None
+    L.run_frame_network_deferred.argtypes = [vp, _f32p]
+    L.run_frame_network_deferred.restype = None
+    L.run_frame_network_flush.argtypes = [vp]
+    L.run_frame_network_flush.restype = None
+    L.lpcnet_synthesize_tail_impl.argtypes = [vp, _i16p, C.c_int, C.c_int]
+    L.lpcnet_synthesize_tail_impl.restype = None
+    L.lpcnet_synthesize_impl.argtypes = [vp, _f32p, _i16p, C.c_int, C.c_int]
+    L.lpcnet_synthesize_impl.restype = None
     L.lpcnet_decoder_get_size.restype = C.c_int
     L.lpcnet_decoder_init.argtypes = [vp]
     L.lpcnet_decoder_create.restype = vp
@@ -134,6 +147,41 @@ class LPCNetState:
         out = np.zeros(n, np.int16)
         self.L.lpcnet_synthesize(self.p, np.ascontiguousarray(features[:NB_FEATURES], np.float32), out, n)
         return out
+
+    # ---- the reference's internal entry points (PLC-facing, src/lpcnet_private.h:125-132)
+    def reset_signal(self):
+        self.L.lpcnet_reset_signal(self.p)
+
+    def run_frame_network(self, features: np.ndarray):
+        ga, gb, lpc = np.zeros(1152, np.float32), np.zeros(48, np.float32), np.zeros(16, np.float32)
+        self.L.run_frame_network(self.p, ga, gb, lpc, np.ascontiguousarray(features[:NB_FEATURES], np.float32))
+        return ga, gb, lpc
+
+    def run_frame_network_deferred(self, features: np.ndarray):
+        self.L.run_frame_network_deferred(self.p, np.ascontiguousarray(features[:NB_FEATURES], np.float32))
+
+    def run_frame_network_flush(self):
+        self.L.run_frame_network_flush(self.p)
+
+    def synthesize_tail_impl(self, n: int = LPCNET_FRAME_SIZE, preload_pcm=None) -> np.ndarray:
+        out = np.zeros(n, np.int16)
+        k = 0 if preload_pcm is None else len(preload_pcm)
+        out[:k] = preload_pcm if k else 0
+        self.L.lpcnet_synthesize_tail_impl(self.p, out, n, k)
+        return out
+
+    def synthesize_impl(self, features: np.ndarray, n: int = LPCNET_FRAME_SIZE, preload_pcm=None) -> np.ndarray:
+        out = np.zeros(n, np.int16)
+        k = 0 if preload_pcm is None else len(preload_pcm)
+        out[:k] = preload_pcm if k else 0
+        self.L.lpcnet_synthesize_impl(self.p, np.ascontiguousarray(features[:NB_FEATURES], np.float32), out, n, k)
+        return out
+
+    def raw_bytes(self) -> bytes:
+        return C.string_at(self.p, self.L.lpcnet_get_size())
+
+    def load_raw_bytes(self, raw: bytes):
+        C.memmove(self.p, raw, self.L.lpcnet_get_size())
 
     def __del__(self):
         try:

@@ -11,6 +11,7 @@
  */
 #include <pthread.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,10 +21,18 @@
 
 #define LPCN_MAGIC 0x4C50434Eu   /* "LPCN" */
 
+#define MAX_FEATURE_BUFFER_SIZE 4     /* src/lpcnet_private.h:26 */
+
 struct LPCNetState {
     uint32_t magic;
     int32_t model_id;                 /* index into the registry, -1 = no model bound */
     lpcn_stream_state s;
+    /* the frame products live in the state like in the reference (src/lpcnet_private.h:36-38), so that
+     * run_frame_network and lpcnet_synthesize_tail_impl can be called separately (PLC, src/lpcnet_plc.c) */
+    float gru_a_condition[LPCN_ROWS_A];
+    float gru_b_condition[LPCN_ROWS_B];
+    float feature_buffer[NB_FEATURES * MAX_FEATURE_BUFFER_SIZE];   /* run_frame_network_deferred queue */
+    int32_t feature_buffer_fill;
 };
 
 struct LPCNetDecState {
@@ -188,7 +197,7 @@ int lpcnet_get_size(void) { return (int)sizeof(LPCNetState); }
 
 void lpcnet_reset(LPCNetState *st)
 {
-    memset(&st->s, 0, sizeof(st->s));
+    memset(&st->s, 0, sizeof(*st) - offsetof(LPCNetState, s));      /* everything behind the model handle, src/lpcnet.c:177-179 */
     st->s.last_exc = 128;             /* lin2ulaw(0), src/lpcnet.c:180 */
     seed_rng(st->s.rng);
 }
@@ -221,30 +230,117 @@ int lpcnet_load_model(LPCNetState *st, const unsigned char *data, int len)
     return 0;
 }
 
+static lpcn_batch_dev *bound_device(const LPCNetState *st, const char *who)
+{
+    if (st->magic != LPCN_MAGIC || st->model_id < 0 || st->model_id >= MAX_MODELS || !g_reg[st->model_id].used) {
+        fprintf(stderr, "%s: no model bound to this state (call lpcnet_load_model first); "
+                        "the HIP engine has no built-in model and no CPU fallback\n", who);
+        abort();
+    }
+    return g_reg[st->model_id].dev;
+}
+
+static void device_failure(const char *who)
+{
+    fprintf(stderr, "%s: device failure: %s\n", who, lpcn_last_error());
+    abort();
+}
+
+/* ---- the reference's internal entry points (src/lpcnet_private.h:125-132), which src/lpcnet_plc.c links to ---- */
+
+/* src/lpcnet.c:226-233 */
+void lpcnet_reset_signal(LPCNetState *st)
+{
+    st->s.deemph_mem = 0;
+    st->s.last_exc = 128;             /* lin2ulaw(0.f) */
+    memset(st->s.last_sig, 0, sizeof(st->s.last_sig));
+    memset(st->s.gru_a, 0, sizeof(st->s.gru_a));
+    memset(st->s.gru_b, 0, sizeof(st->s.gru_b));
+}
+
+/* src/lpcnet.c:82-120: one step of the 100 Hz network; products go to the caller's arrays */
+void run_frame_network(LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features)
+{
+    lpcn_batch_dev *d = bound_device(st, "run_frame_network");
+    float lpc_new[LPCN_LPC_ORDER];      /* `lpc` may point into st->s, which the state download overwrites */
+    pthread_mutex_lock(&g_lock);
+    int rc = lpcn_batch_dev_set_state(d, 0, &st->s);
+    if (!rc) rc = lpcn_batch_dev_run_frames_host(d, features, NB_FEATURES, gru_a_condition, gru_b_condition, lpc_new, 1);
+    if (!rc) rc = lpcn_batch_dev_get_state(d, 0, &st->s);
+    pthread_mutex_unlock(&g_lock);
+    if (rc) device_failure("run_frame_network");
+    memcpy(lpc, lpc_new, sizeof(lpc_new));
+}
+
+/* src/lpcnet.c:122-132: queue a frame (at most kernel_size1 + kernel_size2 - 2 = 4, oldest dropped) */
+void run_frame_network_deferred(LPCNetState *st, const float *features)
+{
+    const int max_buffer_size = MAX_FEATURE_BUFFER_SIZE;
+    if (st->feature_buffer_fill == max_buffer_size)
+        memmove(st->feature_buffer, &st->feature_buffer[NB_FEATURES], sizeof(float) * (size_t)(max_buffer_size - 1) * NB_FEATURES);
+    else
+        st->feature_buffer_fill++;
+    memcpy(&st->feature_buffer[(st->feature_buffer_fill - 1) * NB_FEATURES], features, sizeof(float) * NB_FEATURES);
+}
+
+/* src/lpcnet.c:134-144: run the queued frames, products discarded */
+void run_frame_network_flush(LPCNetState *st)
+{
+    for (int i = 0; i < st->feature_buffer_fill; i++) {
+        float lpc[LPCN_LPC_ORDER], ga[LPCN_ROWS_A], gb[LPCN_ROWS_B];
+        run_frame_network(st, ga, gb, lpc, &st->feature_buffer[i * NB_FEATURES]);
+    }
+    st->feature_buffer_fill = 0;
+}
+
+/* src/lpcnet.c:235-271: N samples from the products held in the state; the first `preload` samples of
+ * `output` are imposed on the synthesis filter (teacher forcing) instead of being written */
+void lpcnet_synthesize_tail_impl(LPCNetState *st, short *output, int N, int preload)
+{
+    if (N <= 0) return;
+    lpcn_batch_dev *d = bound_device(st, "lpcnet_synthesize_tail_impl");
+    if (N > LPCN_FRAME_SIZE || preload < 0 || preload > N) {
+        fprintf(stderr, "lpcnet_synthesize_tail_impl: N=%d preload=%d outside 1..%d / 0..N\n", N, preload, LPCN_FRAME_SIZE);
+        abort();
+    }
+    short frame[LPCN_FRAME_SIZE] = {0};
+    memcpy(frame, output, sizeof(short) * (size_t)preload);
+    pthread_mutex_lock(&g_lock);
+    int rc = lpcn_batch_dev_set_state(d, 0, &st->s);
+    if (!rc) rc = lpcn_batch_dev_set_frame_len(d, N);
+    if (!rc) rc = lpcn_batch_dev_run_tail_host(d, st->gru_a_condition, st->gru_b_condition, st->s.lpc, frame, 1, preload);
+    if (!rc) rc = lpcn_batch_dev_get_state(d, 0, &st->s);
+    pthread_mutex_unlock(&g_lock);
+    if (rc) device_failure("lpcnet_synthesize_tail_impl");
+    /* live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243) */
+    memcpy(output, frame, sizeof(short) * (size_t)N);
+}
+
+/* src/lpcnet.c:273-277 */
+void lpcnet_synthesize_impl(LPCNetState *st, const float *features, short *output, int N, int preload)
+{
+    run_frame_network(st, st->gru_a_condition, st->gru_b_condition, st->s.lpc, features);
+    lpcnet_synthesize_tail_impl(st, output, N, preload);
+}
+
+/* src/lpcnet.c:279-281.  (One fused device pass: frame kernels and sample kernel back to back; equals
+ * lpcnet_synthesize_impl(..., 0) bit for bit, tests/test_gpu_parity.py.) */
 void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)
 {
     if (N <= 0) return;
-    if (st->magic != LPCN_MAGIC || st->model_id < 0 || st->model_id >= MAX_MODELS || !g_reg[st->model_id].used) {
-        fprintf(stderr, "lpcnet_synthesize: no model bound to this state (call lpcnet_load_model first); "
-                        "the HIP engine has no built-in model and no CPU fallback\n");
-        abort();
-    }
+    lpcn_batch_dev *d = bound_device(st, "lpcnet_synthesize");
     if (N > LPCN_FRAME_SIZE) {
         fprintf(stderr, "lpcnet_synthesize: N=%d > %d samples per call is not supported by the HIP engine\n", N, LPCN_FRAME_SIZE);
         abort();
     }
     pthread_mutex_lock(&g_lock);
-    lpcn_batch_dev *d = g_reg[st->model_id].dev;
     short frame[LPCN_FRAME_SIZE];
     int rc = lpcn_batch_dev_set_state(d, 0, &st->s);
     if (!rc) rc = lpcn_batch_dev_set_frame_len(d, N);
     if (!rc) rc = lpcn_batch_dev_run_host(d, features, NB_FEATURES, frame, 1, 0);
     if (!rc) rc = lpcn_batch_dev_get_state(d, 0, &st->s);
     pthread_mutex_unlock(&g_lock);
-    if (rc) {
-        fprintf(stderr, "lpcnet_synthesize: device failure: %s\n", lpcn_last_error());
-        abort();
-    }
+    if (rc) device_failure("lpcnet_synthesize");
     memcpy(output, frame, sizeof(short) * (size_t)N);
 }
 

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"LPCNET_EXPORT[^;(]*?\b(lpcnet_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"LPCNET_EXPORT[^;(]*?\b((?:lpcnet_|run_frame_network)\w*)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(hip_lib):

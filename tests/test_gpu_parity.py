@@ -348,3 +348,59 @@ def test_other_model_shapes_match_oracle(kw, hip_lib):
         _, _, ga, gb = states[n - 1].nnet_state()
         assert np.array_equal(np.array(st.gru_a, np.float32), ga) and np.array_equal(np.array(st.gru_b, np.float32), gb)
         b.close()
+
+
+def test_plc_facing_entry_points(blob_f32, hip_lib):
+    """the reference's internal entry points (src/lpcnet_private.h:125-132), which src/lpcnet_plc.c drives:
+    split frame-network / tail calls, the deferred feature queue, teacher forcing and reset_signal"""
+    T = 9
+    feats = feats_for([5100], T)[0]
+    a = api.LPCNetState(blob_f32)
+    whole = np.concatenate([a.synthesize(feats[t]) for t in range(T)])
+    # 1. run_frame_network + lpcnet_synthesize_tail_impl == lpcnet_synthesize, products == oracle's
+    om = orc.OracleModel(blob_f32)
+    o = om.new_state()
+    b = api.LPCNetState(blob_f32)
+    split = []
+    for t in range(T):
+        frame = np.zeros(160, np.int16)
+        o.L.orc_synthesize(o.p, np.ascontiguousarray(feats[t, :20]), frame, 160, 0)
+        lp, ca, cb = o.frame_products()
+        split.append(b.synthesize_impl(feats[t]))
+        raw = b.raw_bytes()
+        off = 8 + C.sizeof(api.StreamState)
+        got_ca = np.frombuffer(raw, np.float32, 1152, off)
+        got_cb = np.frombuffer(raw, np.float32, 48, off + 1152 * 4)
+        assert np.array_equal(got_ca, ca) and np.array_equal(got_cb, cb)
+        assert np.array_equal(split[-1], frame)
+    assert np.array_equal(np.concatenate(split), whole)
+    # 2. deferred queue: frames pushed and flushed advance the network exactly like direct calls
+    c, d = api.LPCNetState(blob_f32), api.LPCNetState(blob_f32)
+    for t in range(3):
+        c.run_frame_network(feats[t])
+        d.run_frame_network_deferred(feats[t])
+    d.run_frame_network_flush()
+    nstate = 8 + C.sizeof(api.StreamState)               # (the queue itself keeps its stale frames, like the reference's)
+    assert c.raw_bytes()[:nstate] == d.raw_bytes()[:nstate]
+    for t in range(6):                                    # more than 4 queued: the oldest are dropped (src/lpcnet.c:126-127)
+        d.run_frame_network_deferred(feats[t])
+    d.run_frame_network_flush()
+    for t in range(2, 6):
+        c.run_frame_network(feats[t])
+    assert c.raw_bytes()[:nstate] == d.raw_bytes()[:nstate]
+    # 3. teacher forcing through lpcnet_synthesize_impl == the batch preload path; N < 160
+    e = api.LPCNetState(blob_f32)
+    bt = api.LPCNetBatch(1, blob_f32)
+    forced = (np.arange(40) * 37 % 2000 - 1000).astype(np.int16)
+    for t in range(4):
+        pe = e.synthesize_impl(feats[t], 160, forced)
+        buf = np.zeros((1, 160), np.int16); buf[0, :40] = forced
+        pb = bt.synthesize(feats[None, t:t + 1], preload_pcm=buf, preload=40)
+        assert np.array_equal(pe, pb[0])
+    bt.close()
+    # 4. reset_signal clears the signal path and both GRU states, nothing else (src/lpcnet.c:226-233)
+    before = api.StreamState.from_buffer_copy(e.raw_bytes()[8:8 + C.sizeof(api.StreamState)])
+    e.reset_signal()
+    after = api.StreamState.from_buffer_copy(e.raw_bytes()[8:8 + C.sizeof(api.StreamState)])
+    assert not any(after.gru_a) and not any(after.gru_b) and not any(after.last_sig) and after.deemph_mem == 0 and after.last_exc == 128
+    assert list(after.conv1_mem) == list(before.conv1_mem) and after.frame_count == before.frame_count and list(after.rng) == list(before.rng)
