@@ -60,6 +60,11 @@ LPCNET_EXPORT void lpcnet_synthesize(LPCNetState *st, const float *features, sho
  * Unlike the reference the blob is copied to the device and need not outlive the state. */
 LPCNET_EXPORT int lpcnet_load_model(LPCNetState *st, const unsigned char *data, int len);
 
+/* sizeof(LPCNetState) of this engine (== lpcnet_get_size()).  The state is a relocatable POD without pointers; a
+ * caller that embeds it by value (struct LPCNetPLCState, src/lpcnet_private.h:86) can declare
+ *     struct LPCNetState { _Alignas(4) unsigned char opaque[LPCNET_HIP_STATE_BYTES]; };                              */
+#define LPCNET_HIP_STATE_BYTES 8724
+
 /* ---- internal entry points of the reference (src/lpcnet_private.h:125-132).  src/lpcnet_plc.c links to them:
  * exporting them with the same names and meaning lets the unmodified PLC drive this engine.
  * LPCNetState holds the frame products between run_frame_network and lpcnet_synthesize_tail_impl, as in the

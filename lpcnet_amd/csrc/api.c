@@ -35,6 +35,8 @@ struct LPCNetState {
     int32_t feature_buffer_fill;
 };
 
+_Static_assert(sizeof(struct LPCNetState) == LPCNET_HIP_STATE_BYTES, "include/lpcnet.h: LPCNET_HIP_STATE_BYTES is stale");
+
 struct LPCNetDecState {
     LPCNetState lpcnet_state;         /* reference: src/lpcnet_private.h:50-53 */
     float vq_mem[LPCN_NB_BANDS];
