@@ -44,6 +44,11 @@ LPCNET_EXPORT int lpcnet_batch_synthesize_preload(LPCNetBatch *b, const float *f
                                                   int n_frames, int preload);
 /* Codec path: packets [n_streams][n_packets][8] -> pcm [n_streams][n_packets*640] (lpcnet_decode per stream) */
 LPCNET_EXPORT int lpcnet_batch_decode(LPCNetBatch *b, const unsigned char *packets, short *pcm, int n_packets);
+/* the same with device pointers (packets [n][n_packets][8], pcm [n][n_packets*640]), only enqueued on `hip_stream`
+ * (NULL = the batch's own stream): bit unpacking, VQ lookup and interpolation (decode_packet, src/lpcnet_dec.c:81-155)
+ * run in a device kernel; the per-stream VQ memory lives on the device and is cleared by lpcnet_batch_reset */
+LPCNET_EXPORT int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets,
+                                             void *hip_stream);
 
 /* State interchange with the single-stream API (PLC-style snapshot / rollback). */
 LPCNET_EXPORT int lpcnet_batch_export_state(LPCNetBatch *b, int stream, LPCNetState *st);

@@ -46,7 +46,7 @@ struct LPCNetBatch {
     int n, device;
     lpcn_engine *engine;
     lpcn_batch_dev *dev;
-    float *vq_mem;                    /* [n][18] for lpcnet_batch_decode */
+    int cb_version;                   /* g_cb_version of the codebooks on the device (0 = none) */
 };
 
 static __thread char tl_err[512];
@@ -57,6 +57,7 @@ const char *lpcnet_batch_last_error(void) { return tl_err; }
 
 /* ---- VQ codebooks for the codec path (absent generated file ceps_codebooks.c) ---------------- */
 static float *g_cb[4];
+static int g_cb_version;              /* bumped by every lpcnet_hip_set_codebooks: batches re-upload lazily */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
 void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *cb3, const float *cbd)
@@ -69,6 +70,7 @@ void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *c
         g_cb[i] = (float *)malloc(cnt[i] * sizeof(float));
         memcpy(g_cb[i], src[i], cnt[i] * sizeof(float));
     }
+    g_cb_version++;
     pthread_mutex_unlock(&g_lock);
 }
 
@@ -384,7 +386,6 @@ LPCNetBatch *lpcnet_batch_create(int n_streams, int device)
     LPCNetBatch *b = (LPCNetBatch *)calloc(1, sizeof(*b));
     if (!b) return NULL;
     b->n = n_streams; b->device = device;
-    b->vq_mem = (float *)calloc((size_t)n_streams * LPCN_NB_BANDS, sizeof(float));
     return b;
 }
 
@@ -393,7 +394,6 @@ void lpcnet_batch_destroy(LPCNetBatch *b)
     if (!b) return;
     if (b->dev) lpcn_batch_dev_destroy(b->dev);
     if (b->engine) lpcn_engine_destroy(b->engine);
-    free(b->vq_mem);
     free(b);
 }
 
@@ -424,7 +424,6 @@ int lpcnet_batch_load_model(LPCNetBatch *b, const unsigned char *data, int len)
 int lpcnet_batch_reset(LPCNetBatch *b, int first, int count)
 {
     NEED_MODEL(b);
-    if (first >= 0 && count >= 0 && first + count <= b->n) memset(b->vq_mem + (size_t)first * LPCN_NB_BANDS, 0, sizeof(float) * (size_t)count * LPCN_NB_BANDS);
     FWD(lpcn_batch_dev_reset(b->dev, first, count));
 }
 
@@ -448,26 +447,38 @@ int lpcnet_batch_synthesize_device(LPCNetBatch *b, const float *d_features, int 
 
 int lpcnet_batch_sync(LPCNetBatch *b) { NEED_MODEL(b); FWD(lpcn_batch_dev_sync(b->dev)); }
 
+/* the device copy of the VQ codebooks follows lpcnet_hip_set_codebooks() */
+static int batch_codebooks(LPCNetBatch *b)
+{
+    pthread_mutex_lock(&g_lock);
+    int rc = 0;
+    if (!g_cb[0]) { set_err("lpcnet_batch_decode: no VQ codebooks installed (lpcnet_hip_set_codebooks)"); rc = LPCN_E_MODEL; }
+    else if (b->cb_version != g_cb_version) {
+        rc = lpcn_engine_set_codebooks(b->engine, g_cb[0], g_cb[1], g_cb[2], g_cb[3]);
+        if (rc) take_engine_err(); else b->cb_version = g_cb_version;
+    }
+    pthread_mutex_unlock(&g_lock);
+    return rc;
+}
+
+/* packets [n][n_packets][8] (host) -> pcm [n][n_packets*640]; unpacking, VQ lookup and interpolation run on the device */
 int lpcnet_batch_decode(LPCNetBatch *b, const unsigned char *packets, short *pcm, int n_packets)
 {
     NEED_MODEL(b);
     if (n_packets <= 0) { set_err("lpcnet_batch_decode: bad arguments"); return LPCN_E_ARG; }
-    const int T = 4 * n_packets;
-    float *feat = (float *)malloc(sizeof(float) * (size_t)b->n * T * NB_TOTAL_FEATURES);
-    if (!feat) { set_err("out of memory"); return LPCN_E_ARG; }
-    for (int s = 0; s < b->n; s++)
-        for (int p = 0; p < n_packets; p++)
-            if (packet_to_features((float (*)[NB_TOTAL_FEATURES])(feat + ((size_t)s * T + 4 * p) * NB_TOTAL_FEATURES),
-                                   b->vq_mem + (size_t)s * LPCN_NB_BANDS,
-                                   packets + ((size_t)s * n_packets + p) * LPCNET_COMPRESSED_SIZE) != 0) {
-                free(feat);
-                set_err("lpcnet_batch_decode: no VQ codebooks installed (lpcnet_hip_set_codebooks)");
-                return LPCN_E_MODEL;
-            }
-    int rc = lpcn_batch_dev_run_host(b->dev, feat, NB_TOTAL_FEATURES, pcm, T, 0);
-    free(feat);
-    if (rc) take_engine_err();
-    return rc;
+    int rc = batch_codebooks(b);
+    if (rc) return rc;
+    FWD(lpcn_batch_dev_decode_host(b->dev, packets, pcm, n_packets));
+}
+
+/* the same with device pointers, enqueued on the caller's stream (NULL = the batch's own) */
+int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
+{
+    NEED_MODEL(b);
+    if (n_packets <= 0) { set_err("lpcnet_batch_decode_device: bad arguments"); return LPCN_E_ARG; }
+    int rc = batch_codebooks(b);
+    if (rc) return rc;
+    FWD(lpcn_batch_dev_decode(b->dev, d_packets, d_pcm, n_packets, hip_stream));
 }
 
 int lpcnet_batch_export_state(LPCNetBatch *b, int stream, LPCNetState *st)

@@ -9,6 +9,8 @@
 #include "lpcnet_tables_gen.h"
 #include "sample_kernel.hip.h"
 #include "frame_kernels.hip.h"
+#include "decode_kernel.hip.h"
+#include <math.h>
 
 static thread_local char g_err[512] = "";
 extern "C" const char *lpcn_last_error(void) { return g_err; }
@@ -32,6 +34,8 @@ struct lpcn_engine {
     std::vector<void *> allocs;
     LpcnSampleArgs sargs{};        // model part filled at creation
     LpcnFrameModel fmodel{};
+    lpcn::DecodeTables dec{};      // codec path: VQ codebooks + pitch table (set by lpcn_engine_set_codebooks)
+    bool has_codebooks = false;
 };
 
 struct lpcn_batch_dev {
@@ -40,7 +44,10 @@ struct lpcn_batch_dev {
     lpcn_stream_state *d_state = nullptr;
     int *d_fc_base = nullptr;
     float *d_cond_a = nullptr, *d_cond_b = nullptr, *d_lpc = nullptr, *d_cond = nullptr;
-    float *d_feat = nullptr;           // staging for host-pointer runs
+    float *d_feat = nullptr;           // staging for host-pointer runs / decoded feature vectors
+    float *d_vq_mem = nullptr;         // [n][18] VQ memory of the codec path (src/lpcnet_private.h:52)
+    unsigned char *d_packets = nullptr;
+    size_t packets_cap = 0;
     short *d_pcm = nullptr;
     size_t feat_cap = 0, pcm_cap = 0;
     LpcnSampleArgs *d_args = nullptr;
@@ -187,6 +194,23 @@ extern "C" void lpcn_engine_destroy(lpcn_engine *e)
 }
 extern "C" int lpcn_engine_device(const lpcn_engine *e) { return e->device; }
 
+// VQ codebooks of the codec path (the reference's generated ceps_codebooks.c): cb1..3 [1024][17], cb_diff4 [4096][18]
+extern "C" int lpcn_engine_set_codebooks(lpcn_engine *e, const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = 0;
+    if ((rc = upload<float>(e, &e->dec.cb1, cb1, 1024 * 17))) return rc;
+    if ((rc = upload<float>(e, &e->dec.cb2, cb2, 1024 * 17))) return rc;
+    if ((rc = upload<float>(e, &e->dec.cb3, cb3, 1024 * 17))) return rc;
+    if ((rc = upload<float>(e, &e->dec.cb_diff4, cb_diff4, 4096 * 18))) return rc;
+    float pitch[64];
+    for (int k = 0; k < 64; ++k) pitch[k] = (float)(pow(2.f, k / 21.) * 32);      // src/lpcnet_dec.c:107 (PITCH_MIN_PERIOD 32)
+    if ((rc = upload<float>(e, &e->dec.pitch, pitch, 64))) return rc;
+    e->has_codebooks = true;
+    return 0;
+}
+extern "C" int lpcn_engine_has_codebooks(const lpcn_engine *e) { return e->has_codebooks ? 1 : 0; }
+
 // ------------------------------------------------------------------------------------ batches --
 extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n, int max_chunk)
 {
@@ -206,6 +230,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
     AL(b->d_lpc, sizeof(float) * (size_t)n * max_chunk * LPCN_LPC_ORDER);
     AL(b->d_cond, sizeof(float) * (size_t)n * (max_chunk + 4) * LPCN_COND * 2);
     AL(b->d_args, sizeof(LpcnSampleArgs));
+    AL(b->d_vq_mem, sizeof(float) * (size_t)n * LPCN_NB_BANDS);
 #undef AL
     for (auto &ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) return fail(LPCN_E_HIP);
     *out = b;
@@ -219,7 +244,8 @@ extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
     if (!b) return;
     (void)hipSetDevice(b->e->device);
     (void)hipStreamSynchronize(b->e->stream);
-    void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof};
+    void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof,
+                    b->d_vq_mem, b->d_packets};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : b->ev) if (ev) (void)hipEventDestroy(ev);
     delete b;
@@ -250,6 +276,7 @@ extern "C" int lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count)
     for (auto &s : h) host_reset_state(&s);
     HIP_TRY(hipStreamSynchronize(b->e->stream));
     HIP_TRY(hipMemcpy(b->d_state + first, h.data(), sizeof(lpcn_stream_state) * count, hipMemcpyHostToDevice));
+    if (count) HIP_TRY(hipMemset(b->d_vq_mem + (size_t)first * LPCN_NB_BANDS, 0, sizeof(float) * (size_t)count * LPCN_NB_BANDS));
     return 0;
 }
 
@@ -417,6 +444,51 @@ extern "C" int lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features,
     HIP_TRY(hipMemcpyAsync(b->d_feat, features, nfeat * sizeof(float), hipMemcpyHostToDevice, st));
     if (preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pcm, npcm * sizeof(short), hipMemcpyHostToDevice, st));
     rc = lpcn_batch_dev_run(b, b->d_feat, feat_stride, b->d_pcm, n_frames, preload, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(pcm, b->d_pcm, npcm * sizeof(short), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// Codec path: 8-byte packets [stream][packet][8] -> 4 frames each.  Device pointers, work only enqueued.
+extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
+{
+    if (n_packets <= 0) { snprintf(g_err, sizeof(g_err), "bad decode arguments"); return LPCN_E_ARG; }
+    if (!b->e->has_codebooks) { snprintf(g_err, sizeof(g_err), "no VQ codebooks installed (lpcnet_hip_set_codebooks)"); return LPCN_E_MODEL; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->e->stream;
+    const int T = 4 * n_packets;
+    if (hip_stream == nullptr) {
+        int rc = ensure_staging(b, (size_t)b->n * T * LPCN_NB_FEAT, 0);
+        if (rc) return rc;
+    } else if ((size_t)b->n * T * LPCN_NB_FEAT > b->feat_cap) {
+        // growing the staging buffer would synchronise the device: do it once, outside the caller's stream
+        HIP_TRY(hipStreamSynchronize(st));
+        int rc = ensure_staging(b, (size_t)b->n * T * LPCN_NB_FEAT, 0);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(lpcn::decode_kernel, dim3((b->n + 1) / 2), dim3(64), 0, st, b->e->dec, d_packets, b->n, n_packets, b->d_vq_mem,
+                       b->d_feat, LPCN_NB_FEAT);
+    HIP_TRY(hipGetLastError());
+    return lpcn_batch_dev_run(b, b->d_feat, LPCN_NB_FEAT, d_pcm, T, 0, st);
+}
+
+extern "C" int lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char *packets, short *pcm, int n_packets)
+{
+    if (n_packets <= 0) { snprintf(g_err, sizeof(g_err), "bad decode arguments"); return LPCN_E_ARG; }
+    HIP_TRY(hipSetDevice(b->e->device));
+    const size_t nbytes = (size_t)b->n * n_packets * 8, npcm = (size_t)b->n * n_packets * 4 * LPCN_FRAME_SIZE;
+    if (nbytes > b->packets_cap) {
+        if (b->d_packets) (void)hipFree(b->d_packets);
+        b->d_packets = nullptr; b->packets_cap = 0;
+        HIP_TRY(hipMalloc((void **)&b->d_packets, nbytes));
+        b->packets_cap = nbytes;
+    }
+    int rc = ensure_staging(b, 0, npcm);
+    if (rc) return rc;
+    hipStream_t st = b->e->stream;
+    HIP_TRY(hipMemcpyAsync(b->d_packets, packets, nbytes, hipMemcpyHostToDevice, st));
+    rc = lpcn_batch_dev_decode(b, b->d_packets, b->d_pcm, n_packets, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pcm, b->d_pcm, npcm * sizeof(short), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

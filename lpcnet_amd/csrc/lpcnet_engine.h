@@ -140,6 +140,13 @@ int  lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features, int feat_
                              short *pcm, int n_frames, int preload);
 int  lpcn_batch_dev_sync(lpcn_batch_dev *b);
 
+/* Codec path (src/lpcnet_dec.c:81-155 on the device): packets [n][n_packets][8] -> pcm [n][n_packets*640].
+ * The VQ memory of every stream lives on the device and is cleared by lpcn_batch_dev_reset. */
+int  lpcn_engine_set_codebooks(lpcn_engine *e, const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4);
+int  lpcn_engine_has_codebooks(const lpcn_engine *e);
+int  lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream);
+int  lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char *packets, short *pcm, int n_packets);
+
 /* Parity seam (SURVEY.md §7 hard part 9): run only the sample loop with caller-provided frame
  * products (host pointers): cond_a [n][f][1152], cond_b [n][f][48], lpc [n][f][16]. */
 int  lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond_a, const float *cond_b,

@@ -226,6 +226,28 @@ def test_codec_path_matches_reference_golden(blob_f32, golden, hip_lib):
     out = b.decode(pk)
     for s in range(3):
         assert np.array_equal(out[s], golden["packet_pcm_gf"].reshape(-1))
+    # streaming: the VQ memory lives on the device between calls; reset clears it; device-pointer entry point
+    import torch
+    b.reset()
+    P = pk.shape[1]
+    part = np.concatenate([b.decode(pk[:, :2]), b.decode(pk[:, 2:])], axis=1)
+    assert np.array_equal(part, out)
+    b.reset()
+    d_pk = torch.from_numpy(np.ascontiguousarray(pk)).cuda()
+    d_pcm = torch.zeros((3, P * 640), dtype=torch.int16, device="cuda")
+    b.decode_device(d_pk.data_ptr(), d_pcm.data_ptr(), P, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pcm.cpu().numpy(), out)
+    # random packets (every bit pattern is a valid packet): device unpacking == the single-stream host path
+    rng = np.random.default_rng(9)
+    rp = rng.integers(0, 256, size=(2, 5, 8), dtype=np.uint8)
+    b2 = api.LPCNetBatch(2, blob_f32)
+    got = b2.decode(rp)
+    for s in range(2):
+        d1 = api.LPCNetDecState(blob_f32)
+        want = np.concatenate([d1.decode(rp[s, k]) for k in range(5)])
+        assert np.array_equal(got[s], want)
+    b2.close()
     b.close()
 
 
