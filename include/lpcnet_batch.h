@@ -47,6 +47,10 @@ LPCNET_EXPORT int lpcnet_batch_decode(LPCNetBatch *b, const unsigned char *packe
 /* the same with device pointers (packets [n][n_packets][8], pcm [n][n_packets*640]), only enqueued on `hip_stream`
  * (NULL = the batch's own stream): bit unpacking, VQ lookup and interpolation (decode_packet, src/lpcnet_dec.c:81-155)
  * run in a device kernel; the per-stream VQ memory lives on the device and is cleared by lpcnet_batch_reset */
+/* LPC_GAMMA (bandwidth expansion of the LPC filter, lpc_weighting src/freq.c:299-308) is a compile-time constant of the
+ * reference's generated nnet_data.h, not part of the weight blob; models trained with --lpc-gamma != 1 set it after
+ * lpcnet_batch_load_model.  gamma in (0, 1], default 1. */
+LPCNET_EXPORT int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma);
 LPCNET_EXPORT int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets,
                                              void *hip_stream);
 

@@ -481,6 +481,13 @@ int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, s
     FWD(lpcn_batch_dev_decode(b->dev, d_packets, d_pcm, n_packets, hip_stream));
 }
 
+/* LPC_GAMMA of the model (a #define of the reference's generated nnet_data.h, not in the blob); default 1 */
+int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma)
+{
+    NEED_MODEL(b);
+    FWD(lpcn_engine_set_lpc_gamma(b->engine, gamma));
+}
+
 int lpcnet_batch_export_state(LPCNetBatch *b, int stream, LPCNetState *st)
 {
     NEED_MODEL(b);

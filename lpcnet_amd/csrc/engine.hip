@@ -210,6 +210,15 @@ extern "C" int lpcn_engine_set_codebooks(lpcn_engine *e, const float *cb1, const
     return 0;
 }
 extern "C" int lpcn_engine_has_codebooks(const lpcn_engine *e) { return e->has_codebooks ? 1 : 0; }
+// LPC_GAMMA is a compile-time constant of the reference's generated nnet_data.h (lpc_weighting, src/freq.c:299-308), not
+// part of the weight blob: models trained with --lpc-gamma != 1 set it here.
+extern "C" int lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma)
+{
+    if (!(gamma > 0.f && gamma <= 1.f)) { snprintf(g_err, sizeof(g_err), "lpc_gamma must be in (0, 1]"); return LPCN_E_ARG; }
+    e->lpc_gamma = gamma;
+    e->fmodel.lpc_gamma = gamma;
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------ batches --
 extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n, int max_chunk)

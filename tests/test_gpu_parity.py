@@ -426,3 +426,20 @@ def test_plc_facing_entry_points(blob_f32, hip_lib):
     after = api.StreamState.from_buffer_copy(e.raw_bytes()[8:8 + C.sizeof(api.StreamState)])
     assert not any(after.gru_a) and not any(after.gru_b) and not any(after.last_sig) and after.deemph_mem == 0 and after.last_exc == 128
     assert list(after.conv1_mem) == list(before.conv1_mem) and after.frame_count == before.frame_count and list(after.rng) == list(before.rng)
+
+
+def test_lpc_gamma_variant(blob_f32, hip_lib):
+    """LPC_GAMMA != 1 (a #define of the reference's generated header): bandwidth-expanded LPC on the device == oracle"""
+    n, T = 2, 8
+    feats = feats_for([8100, 8101], T)
+    om = orc.OracleModel(blob_f32, lpc_gamma=0.9)
+    want = np.stack([om.new_state().synthesize(feats[s]) for s in range(n)])
+    b = api.LPCNetBatch(n, blob_f32)
+    b.set_lpc_gamma(0.9)
+    got = b.synthesize(feats)
+    assert np.array_equal(got, want)
+    plain, _ = oracle_run(blob_f32, feats)
+    assert not np.array_equal(plain, want)
+    with pytest.raises(api.LPCNetError):
+        b.set_lpc_gamma(1.5)
+    b.close()

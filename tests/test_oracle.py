@@ -166,3 +166,13 @@ def test_reference_flavours_diverge_as_documented(blob_f32):
     a = ref.RefLib("gf").synthesize_file(blob_f32, f)
     b = ref.RefLib("af").synthesize_file(blob_f32, f)
     assert a.shape == b.shape and not np.array_equal(a, b)
+
+
+@pytest.mark.skipif(not ref.available("gg"), reason="oracle/_ref gamma flavour not built (needs /root/reference)")
+def test_lpc_gamma_variant_matches_reference(blob_f32):
+    """LPC_GAMMA 0.9 (lpc_weighting, src/freq.c:299-308): the oracle's parameter == the reference compiled with that #define"""
+    f = synth.make_features(1234, 40)
+    want = ref.RefLib("gg").new_state(blob_f32).synthesize(f)
+    got = orc.OracleModel(blob_f32, lpc_gamma=0.9).new_state().synthesize(f)
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got, orc.OracleModel(blob_f32).new_state().synthesize(f))
