@@ -128,7 +128,7 @@ static int pack_gru_a(lpcn_model_host *m)
             else {
                 /* a "first" wave keeps two gather register sets in flight while its items run: one more slot only */
                 cost[best] = (slot_max[s] > G ? slot_max[s] : G) + 2;
-                maxslots[best] = 2;
+                maxslots[best] = m->is_int8 ? 3 : 2;     /* (the int8 kernel has registers for a third gather set) */
             }
         }
     }
