@@ -69,7 +69,7 @@ struct LpcnSampleArgs {
 #ifndef LPCN_ENABLE_PROF
 #define LPCN_ENABLE_PROF 0
 #endif
-#define LPCN_DBG_STRIDE 1600    // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,pred; [448..1600) GRU-A pre-activations
+#define LPCN_DBG_STRIDE 1600    // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,pred, leader clocks barrier->publish; [448..1600) GRU-A pre-activations
 
 namespace lpcn {
 
@@ -188,6 +188,17 @@ template <int S> struct XVec;
 template <> struct XVec<1> { typedef int type; };
 template <> struct XVec<2> { typedef int type __attribute__((ext_vector_type(2))); };
 template <> struct XVec<4> { typedef int type __attribute__((ext_vector_type(4))); };
+
+// value of lane J of the caller's 16-lane row (DPP row_newbcast); the compiler folds it into the consuming VALU op
+template <int J> __device__ __forceinline__ float row_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xf, 0xf, false));
+}
+template <int J> __device__ __forceinline__ float lpc_chain(float r, float prod)
+{
+    if constexpr (J < LPCN_LPC_ORDER) return lpc_chain<J + 1>(r - row_bcast<J>(prod), prod);
+    else return r;
+}
 
 template <int S, int NW, bool I8>
 __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
@@ -349,25 +360,27 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
     auto row_shr1 = [](float v, float fill) {               // value of the previous lane of the 16-lane row; lane 0 gets `fill`
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
     };
-    auto open_sample = [&](const bool live, const float newest, const int exc) {     // wave 0, lanes < 16*S
+    // `prod` = this lane's term s_j*a_j of the prediction (tap j); `per_frame`: also (re)write the stream's live flag
+    auto open_sample = [&](const bool live, const float newest, const float prod, const int exc, const bool per_frame) {   // wave 0, lanes < 16*S
         int t_ = tid0;
         LPCN_REMAT_V(t_);
         const int lrow = (t_ & 63) >> 4, tap = t_ & 15;
-        // pred = ((0 - s0*a0) - s1*a1) - ... in tap order: lane j is correct from step j on, lane 15 after 16 steps
-        const float prod = hist * sm_lpc[t_];                // sm_lpc is [stream][16] = [lane] for wave 0
-        float r = 0.f;
-#pragma unroll
-        for (int k = 0; k < LPCN_LPC_ORDER; ++k) r = row_shr1(r, 0.f) - prod;
-        // mu-law index of the newest sample (tap 0) and of the prediction (tap 15) in one pass
-        const int u = lpcn_lin2ulaw(tap == 15 ? r : newest);
-        unsigned char *ib = smem + L::idx + lrow * 4;       // (sig, pred, exc) indices packed into one word per stream
-        if (live) {
-            if (tap == 15) { sm_lead[lrow * 8 + 0] = r; ib[1] = (unsigned char)u; }
-            if (tap == 0) { ib[0] = (unsigned char)u; ib[2] = (unsigned char)exc; }
-        } else if (tap == 0) {
-            sm_idx[lrow] = 0;
+        // pred = ((0 - s0*a0) - s1*a1) - ... in tap order (src/lpcnet.c:252): every lane of the row runs the whole chain,
+        // taking product j from lane j of its row through a DPP row broadcast folded into the subtract -- the
+        // broadcast operand does not depend on the chain, so the 16 steps cost only the add latency
+        const float r = lpc_chain<0>(0.f, prod);
+        // mu-law index of the newest sample (even taps) and of the prediction (odd taps) in one pass; tap 0 collects both
+        const int u = lpcn_lin2ulaw((tap & 1) ? r : newest);
+        const int u_pred = __builtin_amdgcn_mov_dpp(u, 0xB1, 0xf, 0xf, true);      // neighbour lane (quad_perm [1,0,3,2])
+        if (tap == 0) {
+            if (live) {
+                sm_lead[lrow * 8 + 0] = r;
+                sm_idx[lrow] = u | (u_pred << 8) | (exc << 16);     // (sig, pred, exc) indices packed into one word per stream
+            } else {
+                sm_idx[lrow] = 0;
+            }
+            if (per_frame) sm_idx[S + lrow] = live ? 1 : 0;
         }
-        if (tap == 0) sm_idx[S + lrow] = live ? 1 : 0;
     };
     auto draw_thresholds = [&](const int ls) {
         int *li = (int *)sm_lead + ls * 8;
@@ -442,7 +455,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
         }
         __syncthreads();        // sm_lpc visible to the leaders
         ++seq;
-        if (tid0 < 16 * S) { open_sample(live, hist, ((const int *)sm_lead)[LPCN_LROW * 8 + 2]); publish_indices(); }
+        if (tid0 < 16 * S) {
+            open_sample(live, hist, hist * sm_lpc[tid0], ((const int *)sm_lead)[LPCN_LROW * 8 + 2], true);   // sm_lpc is [stream][16] = [lane] for wave 0
+            publish_indices();
+        }
         if (tid0 >= 64 && tid0 < 64 + S && live) draw_thresholds(tid0 - 64);
         __syncthreads();
         int live_mask = 0;                                   // bit s: stream s produces samples in this frame
@@ -940,6 +956,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     if (lane == 0) sm_mask[s * 8 + wave] = m;
                 }
             }
+            // wave 0, before it waits at the barrier: the prediction terms of the next sample that do not involve the
+            // sample about to be drawn -- tap j >= 1 will hold today's tap j-1 (src/lpcnet.c:252,262)
+            float lpc_tap = 0.f, prod_old = 0.f;
+            if (tid < 16 * S) {
+                lpc_tap = sm_lpc[tid];
+                prod_old = row_shr1(hist, 0.f) * lpc_tap;
+            }
             __syncthreads();                                                   // B4
             LPCN_PROF(3);
 
@@ -948,29 +971,39 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             // sample) work here; everybody else is already in the next sample's GRU-A.
             const bool more = smp + 1 < frame_len;
             if (more) ++seq;
+            unsigned long long t_b4 = 0;
+            if (Ap->dbg) t_b4 = __builtin_amdgcn_s_memtime();                 // tests: leader latency barrier -> publish
             if (tid < 16 * S) {
                 const int lrow = (tid & 63) >> 4, tap = tid & 15;
                 float pcm = 0.f, deemph = 0.f;
                 int exc = 0;
                 if (live) {                                  // (all 16 lanes of a stream's row do the same walk)
-                    const unsigned long long *mk = sm_mask + lrow * 8;
-                    const unsigned long long m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3];
-                    const unsigned long long m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
+                    // the stream's 255 decision bits = 16 dwords: node i was evaluated by wave i>>5 and sits at ballot bit
+                    // 2*(i&31), i.e. dword i>>4, bit 2*(i&15).  (32-bit selects and bit-field extracts: no 64-bit shifts.)
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    const u4 *mk = (const u4 *)(sm_mask + lrow * 8);
+                    const u4 qa = mk[0], qb = mk[1], qc = mk[2], qd = mk[3];
+                    const float pred = sm_lead[lrow * 8 + 0];           // (issued together with the mask reads)
+                    deemph = sm_lead[lrow * 8 + 1];
+                    auto bit_of = [](unsigned word, int k) { return (int)((word >> (2 * k)) & 1u); };
                     int val = 0;
-                    // node i was evaluated by wave i>>5 and sits at ballot bit 2*(i&31)
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const int i = (1 << b) | val;
-                        unsigned long long mw;
-                        if (b <= 4) mw = m0;
-                        else if (b == 5) mw = m1;
-                        else if (b == 6) mw = (i & 32) ? m3 : m2;
-                        else { const int q = (i >> 5) & 3; mw = q == 0 ? m4 : (q == 1 ? m5 : (q == 2 ? m6 : m7)); }
-                        val = (val << 1) | (int)((mw >> (2 * (i & 31))) & 1ull);
+                    for (int b = 0; b < 4; ++b) val = (val << 1) | bit_of(qa[0], (1 << b) | val);        // nodes 1..15
+                    val = (val << 1) | bit_of(qa[1], val);                                               // nodes 16..31
+                    val = (val << 1) | bit_of((val & 16) ? qa[3] : qa[2], val & 15);                     // nodes 32..63
+                    {
+                        const int k = val >> 4;                                                          // nodes 64..127: dwords 4..7
+                        const unsigned lo = (k & 1) ? qb[1] : qb[0], hi = (k & 1) ? qb[3] : qb[2];
+                        val = (val << 1) | bit_of((k & 2) ? hi : lo, val & 15);
+                    }
+                    {
+                        const int k = val >> 4;                                                          // nodes 128..255: dwords 8..15
+                        const unsigned a0 = (k & 1) ? qc[1] : qc[0], a1 = (k & 1) ? qc[3] : qc[2];
+                        const unsigned a2 = (k & 1) ? qd[1] : qd[0], a3 = (k & 1) ? qd[3] : qd[2];
+                        const unsigned b0 = (k & 2) ? a1 : a0, b1 = (k & 2) ? a3 : a2;
+                        val = (val << 1) | bit_of((k & 4) ? b1 : b0, val & 15);
                     }
                     exc = val;
-                    const float pred = sm_lead[lrow * 8 + 0];
-                    deemph = sm_lead[lrow * 8 + 1];
                     if (smp < preload) {                                        // src/lpcnet.c:256-258
                         const float x = (float)sm_pcm[lrow * LPCN_FRAME_SIZE + smp];
                         exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
@@ -989,7 +1022,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     d[1] = (float)(sm_idx[0] & 0xFF); d[2] = (float)((sm_idx[0] >> 8) & 0xFF);
                 }
                 // the next sample's indices first: the other waves are waiting for them
-                if (more) { open_sample(live, pcm, exc); publish_indices(); }
+                if (more) { open_sample(live, pcm, tap == 0 ? pcm * lpc_tap : prod_old, exc, false); publish_indices(); }
+                if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live)
+                    Ap->dbg[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 405] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_b4);
                 if (tap == 0) {
                     if (live) {
                         if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
