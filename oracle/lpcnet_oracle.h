@@ -8,7 +8,7 @@
  * Pinning: the reference holds no golden vectors for this path ("parity unpinned" by its own
  * tests).  This restatement is therefore pinned against the reference itself,
  * compiled from its own sources by oracle/Makefile into oracle/_ref (flavours gf/gi), and
- * against fixtures generated from those builds (tests/golden/, tools/make_golden.py).
+ * against fixtures generated from those builds (tests/golden/, tests/tools/make_golden.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this code.
  * It must be compiled with -ffp-contract=off (the Makefile does).

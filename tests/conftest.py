@@ -32,7 +32,7 @@ def blob_i8():
 @pytest.fixture(scope="session")
 def golden():
     if not os.path.exists(GOLDEN):
-        pytest.skip("golden fixtures missing (tools/make_golden.py)")
+        pytest.skip("golden fixtures missing (tests/tools/make_golden.py)")
     return np.load(GOLDEN)
 
 

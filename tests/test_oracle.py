@@ -1,6 +1,6 @@
 """CPU tests of the checker itself: the plain-C oracle (oracle/lpcnet_oracle.c) against
  (1) the committed golden fixtures, which are outputs of the REAL reference compiled from its own
-     sources (tools/make_golden.py), and
+     sources (tests/tools/make_golden.py), and
  (2) the real reference directly, when oracle/_ref is present (this container; on the GPU box the
      prebuilt .so travels with the snapshot).
 The reference has no golden vectors of its own for this path."""

@@ -2,7 +2,7 @@
 """Bring-up check on a GPU box: HIP engine vs the CPU oracle, seam by seam."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lpcnet_amd import synth, api
 from oracle import orc
 

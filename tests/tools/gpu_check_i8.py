@@ -2,7 +2,7 @@
 """Bring-up check of the int8 engine: per-sample GRU states of stream 0 vs the oracle."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lpcnet_amd import synth, api
 from oracle import orc
 

@@ -2,7 +2,7 @@
 """Throughput sweep over (streams, streams-per-workgroup); checks a few streams against the oracle."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lpcnet_amd import synth, api
 from oracle import orc
 

@@ -1,6 +1,7 @@
 """Clocks from the tree barrier to the publication of the next sample's indices (wave 0), from the debug trace."""
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from lpcnet_amd import synth, api
 for fl in ("float", "int8"):
     blob = synth.blob_bytes(synth.make_model(flavour=fl))

@@ -4,14 +4,14 @@
 holds no golden vectors for this path, so these fixtures are its pinned outputs:
 they travel to the GPU box, where /root/reference does not exist.
 
-    make -C oracle ref && python tools/make_golden.py
+    make -C oracle ref && python tests/tools/make_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from lpcnet_amd import synth  # noqa: E402
 from oracle import ref  # noqa: E402
