@@ -14,18 +14,26 @@
 // Mapping (one workgroup = 8 waves = 512 lanes, S interleaved streams, S in {1,2,4}):
 //   * GRU-A recurrent weights (177 KB fp32 > 160 KB LDS) live in VGPRs for the whole launch:
 //     each lane owns <=3 output rows ("slots", dealt by model_pack.c so that the 64 rows of a
-//     wave-slot have similar block counts) as NW float4 items.
+//     wave-slot have similar block counts) as NW items (float4, or one dword of 4 int8).
 //   * GRU-A state h (S x 384) lives in LDS as [block p][stream][4]; the 8 lanes of a row group
 //     need the same 16*S bytes, so each lane of a quad fetches ONE stream's 16 B (a single
 //     ds_read_b128 per item) and the other three streams arrive through DPP quad_perm
 //     broadcasts folded into the multiplies -- LDS traffic is 1/S of the naive scheme.
+//     int8 blobs: the state is quantised once per sample; v_dot4_i32_i8 per (item, stream).
 //   * GRU-B input weights (<=73.7 KB) + recurrent matrix live in LDS; one wave per stream, one
 //     lane per output row, gates exchanged with wave shuffles (no barrier).
 //   * dual-FC tree: all 255 nodes x 2 channels are evaluated in parallel (lane = node,channel;
-//     18 weight VGPRs), a ballot per wave yields the 255 decision bits, and the stream's leader
-//     lane walks 8 levels in registers.  Speculative evaluation is exact: every node's logit is
-//     a pure function of the GRU-B state.
-//   * leader lane per stream: LPC prediction, mu-law, KISS99 thresholds, de-emphasis, PCM.
+//     18 weight VGPRs), a ballot per wave yields the 255 decision bits.  Speculative evaluation
+//     is exact: every node's logit is a pure function of the GRU-B state.
+//   * wave 0 leads: the 16 lanes of row s walk stream s's tree and hold its 16-sample LPC history
+//     (lane = tap; DPP row shift / row broadcast for the prediction), one mu-law pass, PCM.
+//     Wave 1 draws the KISS99 thresholds of the next sample.
+//
+// Schedule of one sample (4 workgroup barriers B1..B4):
+//   P1 GRU-A rows | B1 | P2 gates | B2 | P3 GRU-B (waves < S)  ||  next sample's candidate-only
+//   slot on waves 4..7 | B3 | P4 tree | B4 | leader publishes the next sample's mu-law indices
+//   through an LDS flag -- no barrier: the other waves are already in P1, running what needs
+//   neither the indices nor the gathered embedding rows, then poll the flag and gather.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
