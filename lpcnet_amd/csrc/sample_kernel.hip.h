@@ -642,6 +642,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     if constexpr (I8) acc[s] = acc[s] * QS;
                 }
             }
+            if (tid0 >= 256) __builtin_amdgcn_s_setprio(2);    // the younger wave of each SIMD pair sees its gather last: let it catch up
             LPCN_PROF(10);     // gather issue + (light waves) wait + start values
 #pragma unroll
             for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             LPCN_PROF(6);      // slots: begin + items + end
             __syncthreads();                                                   // B1
             LPCN_PROF(0);
@@ -786,6 +788,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
             if (wave < S) {
+                __builtin_amdgcn_s_setprio(3);                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
                 const int s = wave;
                 const int r = lane < RB ? lane : RB - 1;
                 const int g = r >> 3, ri = r & 7;
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
 #undef LPCN_SB
                 }
                 LPCN_PROF(8);      // GRU-B input mat-vec
+                __builtin_amdgcn_s_setprio(0);
                 // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
                 const float sg = lpcn_sigmoid(zrh + rec, sm_tansig);
                 const float r_gate = __shfl(sg, 16 + (lane & 15));

@@ -1,0 +1,23 @@
+// which SIMD does wave w of a 512-thread workgroup land on?  (HW_ID: wave_id[3:0], simd_id[5:4], cu_id[11:8] on gfx9)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+__global__ __launch_bounds__(512) void k(unsigned *out)
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = v;
+}
+int main()
+{
+    unsigned *d, h[64];
+    hipMalloc(&d, sizeof(h));
+    hipLaunchKernelGGL(k, dim3(4), dim3(512), 150000, 0, d);
+    hipDeviceSynchronize();
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    for (int b = 0; b < 4; ++b) {
+        printf("block %d:", b);
+        for (int w = 0; w < 8; ++w) printf("  w%d simd%u slot%u cu%u", w, (h[b * 8 + w] >> 4) & 3, h[b * 8 + w] & 15, (h[b * 8 + w] >> 8) & 15);
+        printf("\n");
+    }
+    return 0;
+}
