@@ -7,8 +7,8 @@ DST = os.path.join(ROOT, "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 def one(pattern):
-    f = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return f[0] if f else None
+    f = glob.glob(os.path.join(SRC, pattern), recursive=True)       # gpurun merges runs: take the newest
+    return max(f, key=os.path.getmtime) if f else None
 
 def counter_avg(dirname, counter):
     f = one(f"{dirname}/**/*counter_collection.csv")
