@@ -51,6 +51,9 @@ LPCNET_EXPORT int lpcnet_batch_decode(LPCNetBatch *b, const unsigned char *packe
  * reference's generated nnet_data.h, not part of the weight blob; models trained with --lpc-gamma != 1 set it after
  * lpcnet_batch_load_model.  gamma in (0, 1], default 1. */
 LPCNET_EXPORT int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma);
+/* END2END models: the reference's compile-time END2END (src/lpcnet.c:56-80,107-108) -- the LPC filter comes from the
+ * first 16 conditioning outputs (reflection coefficients, rc2lpc) instead of the cepstrum; set after lpcnet_batch_load_model */
+LPCNET_EXPORT int lpcnet_batch_set_end2end(LPCNetBatch *b, int on);
 LPCNET_EXPORT int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets,
                                              void *hip_stream);
 

@@ -488,6 +488,13 @@ int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma)
     FWD(lpcn_engine_set_lpc_gamma(b->engine, gamma));
 }
 
+/* END2END models (LPC from the network's reflection coefficients); a #define of the reference, not in the blob */
+int lpcnet_batch_set_end2end(LPCNetBatch *b, int on)
+{
+    NEED_MODEL(b);
+    FWD(lpcn_engine_set_end2end(b->engine, on));
+}
+
 int lpcnet_batch_export_state(LPCNetBatch *b, int stream, LPCNetState *st)
 {
     NEED_MODEL(b);

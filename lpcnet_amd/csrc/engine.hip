@@ -180,6 +180,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
         if ((rc = upload<short>(e, &fm.tab_bitrev, src, 320))) return fail(rc);
     }
     fm.lpc_gamma = m->lpc_gamma;
+    fm.end2end = 0;
     *out = e;
     return 0;
 }
@@ -212,6 +213,12 @@ extern "C" int lpcn_engine_set_codebooks(lpcn_engine *e, const float *cb1, const
 extern "C" int lpcn_engine_has_codebooks(const lpcn_engine *e) { return e->has_codebooks ? 1 : 0; }
 // LPC_GAMMA is a compile-time constant of the reference's generated nnet_data.h (lpc_weighting, src/freq.c:299-308), not
 // part of the weight blob: models trained with --lpc-gamma != 1 set it here.
+// END2END is a compile-time switch of the reference (src/lpcnet.c:56-80,107-108), not part of the weight blob
+extern "C" int lpcn_engine_set_end2end(lpcn_engine *e, int on)
+{
+    e->fmodel.end2end = on != 0;
+    return 0;
+}
 extern "C" int lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma)
 {
     if (!(gamma > 0.f && gamma <= 1.f)) { snprintf(g_err, sizeof(g_err), "lpc_gamma must be in (0, 1]"); return LPCN_E_ARG; }

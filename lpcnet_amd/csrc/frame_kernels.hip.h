@@ -25,6 +25,7 @@ struct LpcnFrameModel {
     const float *tab_tansig, *tab_idct, *tab_tw;
     const short *tab_bitrev;
     float lpc_gamma;
+    int end2end;                 // END2END model: LPC = rc2lpc(first 16 conditioning outputs), no cepstral LPC, no delay line
 };
 
 namespace lpcn {
@@ -57,9 +58,11 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
     if (i < LPCN_LPC_ORDER) {
         float g = M.lpc_gamma, gi = g;
         for (int k = 0; k < i; ++k) gi *= g;
-        lpc_out[((size_t)stream * n_frames + 0) * LPCN_LPC_ORDER + i] = st->old_lpc[1][i] * gi;
-        if (n_frames >= 2) lpc_out[((size_t)stream * n_frames + 1) * LPCN_LPC_ORDER + i] = st->old_lpc[0][i] * gi;
-        else st->old_lpc[1][i] = st->old_lpc[0][i];
+        if (!M.end2end) {
+            lpc_out[((size_t)stream * n_frames + 0) * LPCN_LPC_ORDER + i] = st->old_lpc[1][i] * gi;
+            if (n_frames >= 2) lpc_out[((size_t)stream * n_frames + 1) * LPCN_LPC_ORDER + i] = st->old_lpc[0][i] * gi;
+            else st->old_lpc[1][i] = st->old_lpc[0][i];
+        }
     }
     __syncthreads();
 
@@ -355,6 +358,27 @@ __global__ __launch_bounds__(64 * LPC_WAVES) void lpc_kernel(LpcnFrameModel M, i
     }
 }
 
+// END2END models (src/lpcnet.c:56-80,107-108): the first 16 outputs of the conditioning network are reflection
+// coefficients; step-up recursion to LPC, then the LPC_GAMMA weighting.  One thread per (stream, frame).
+__global__ __launch_bounds__(64) void rc2lpc_kernel(LpcnFrameModel M, int n_items, const float *cond /*[item][128]*/, float *lpc_out /*[item][16]*/)
+{
+    const int item = blockIdx.x * 64 + threadIdx.x;
+    if (item >= n_items) return;
+    float tmp[LPCN_LPC_ORDER], ntmp[LPCN_LPC_ORDER];
+#pragma unroll
+    for (int i = 0; i < LPCN_LPC_ORDER; ++i) { tmp[i] = cond[(size_t)item * CN + i]; ntmp[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < LPCN_LPC_ORDER; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i - 1; ++j) ntmp[j] = tmp[j] + tmp[i] * tmp[i - j - 1];
+#pragma unroll
+        for (int k = 0; k <= i - 1; ++k) tmp[k] = ntmp[k];
+    }
+    float g = M.lpc_gamma, gi = g;
+#pragma unroll
+    for (int k = 0; k < LPCN_LPC_ORDER; ++k) { lpc_out[(size_t)item * LPCN_LPC_ORDER + k] = tmp[k] * gi; gi *= g; }
+}
+
 }  // namespace lpcn
 
 static inline int lpcn_launch_frame_kernels(const LpcnFrameModel &M, hipStream_t st, int n, int n_frames, const float *d_feat,
@@ -366,6 +390,9 @@ static inline int lpcn_launch_frame_kernels(const LpcnFrameModel &M, hipStream_t
     const int tiles = (n_frames + lpcn::FT - 1) / lpcn::FT;
     hipLaunchKernelGGL(lpcn::frame_proj_kernel, dim3(n * tiles), dim3(128), 0, st, M, n_frames, tiles, (const float *)d_cond, d_cond_a, d_cond_b);
     const size_t items = (size_t)n * n_frames;
+    if (M.end2end)
+        hipLaunchKernelGGL(lpcn::rc2lpc_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, M, (int)items, (const float *)d_cond, d_lpc);
+    else
     hipLaunchKernelGGL(lpcn::lpc_kernel, dim3((unsigned)((items + lpcn::LPC_WAVES - 1) / lpcn::LPC_WAVES)), dim3(64 * lpcn::LPC_WAVES), 0, st,
                        M, n, n_frames, d_feat, feat_stride, feat_stream_stride, d_state, d_lpc);
     hipError_t e = hipGetLastError();

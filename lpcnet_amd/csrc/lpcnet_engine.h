@@ -144,6 +144,7 @@ int  lpcn_batch_dev_sync(lpcn_batch_dev *b);
  * The VQ memory of every stream lives on the device and is cleared by lpcn_batch_dev_reset. */
 int  lpcn_engine_set_codebooks(lpcn_engine *e, const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4);
 int  lpcn_engine_has_codebooks(const lpcn_engine *e);
+int  lpcn_engine_set_end2end(lpcn_engine *e, int on);              /* END2END of the model's nnet_data.h (default off) */
 int  lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma);     /* LPC_GAMMA of the model's nnet_data.h (default 1) */
 int  lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream);
 int  lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char *packets, short *pcm, int n_packets);

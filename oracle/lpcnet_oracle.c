@@ -26,6 +26,7 @@
  * ====================================================================================== */
 struct orc_model {
     int is_int8;
+    int end2end;
     int nb_a, nb_b;                     /* number of 8x4 blocks in GRU-A / GRU-B input matrix */
     float lpc_gamma;
     const float *emb_sig, *emb_pred, *emb_exc;         /* [256][3*N_A] pre-multiplied tables  */
@@ -114,6 +115,7 @@ orc_model *orc_model_parse(const unsigned char *blob, int len, float lpc_gamma)
     if (n <= 0) return NULL;
     m = (orc_model *)calloc(1, sizeof(*m));
     m->lpc_gamma = lpc_gamma;
+    m->end2end = 0;
 #define F(field, name, count) if (!(m->field = (const float *)need(recs, n, name, (count) * 4))) goto fail
     F(emb_sig,  "gru_a_embed_sig_weights",  256 * 3 * N_A);
     F(emb_pred, "gru_a_embed_pred_weights", 256 * 3 * N_A);
@@ -161,6 +163,7 @@ fail:
 
 void orc_model_free(orc_model *m) { free(m); }
 int  orc_model_is_int8(const orc_model *m) { return m->is_int8; }
+void orc_model_set_end2end(orc_model *m, int on) { m->end2end = on != 0; }      /* the reference's compile-time END2END */
 int  orc_model_nb_blocks(const orc_model *m, int which) { return which ? m->nb_b : m->nb_a; }
 
 /* ======================================================================================
@@ -493,10 +496,22 @@ void orc_frame_network(orc_state *st, const float *features, float *cond_a, floa
     dense_layer(cond, m->dense2_w, m->dense2_b, COND, COND, d1, 1);
     dense_layer(cond_a, m->a_dense_w, m->a_dense_b, COND, 3 * N_A, cond, 0);
     dense_layer(cond_b, m->b_dense_w, m->b_dense_b, COND, 3 * N_B, cond, 0);
-    /* two-frame LPC delay line, src/lpcnet.c:110-112 */
-    memcpy(lpc, st->old_lpc[ORC_FEATURES_DELAY - 1], LPCO * sizeof(float));
-    memmove(st->old_lpc[1], st->old_lpc[0], (ORC_FEATURES_DELAY - 1) * LPCO * sizeof(float));
-    orc_lpc_from_cepstrum(st->old_lpc[0], features);
+    if (m->end2end) {
+        /* END2END models: the first 16 conditioning outputs are reflection coefficients, src/lpcnet.c:56-80,107-108 */
+        float tmp[LPCO], ntmp[LPCO] = {0};
+        int j, k;
+        memcpy(tmp, cond, sizeof(tmp));
+        for (i = 0; i < LPCO; i++) {
+            for (j = 0; j <= i - 1; j++) ntmp[j] = tmp[j] + tmp[i] * tmp[i - j - 1];
+            for (k = 0; k <= i - 1; k++) tmp[k] = ntmp[k];
+        }
+        memcpy(lpc, tmp, sizeof(tmp));
+    } else {
+        /* two-frame LPC delay line, src/lpcnet.c:110-112 */
+        memcpy(lpc, st->old_lpc[ORC_FEATURES_DELAY - 1], LPCO * sizeof(float));
+        memmove(st->old_lpc[1], st->old_lpc[0], (ORC_FEATURES_DELAY - 1) * LPCO * sizeof(float));
+        orc_lpc_from_cepstrum(st->old_lpc[0], features);
+    }
     {   /* src/freq.c:299-308 */
         float g = m->lpc_gamma, gi = g;
         for (i = 0; i < LPCO; i++) { lpc[i] *= gi; gi *= g; }

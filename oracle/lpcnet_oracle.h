@@ -38,6 +38,7 @@ typedef struct orc_state orc_state;
  * record is malformed or an array is missing / mis-sized (src/parse_lpcnet_weights.c:124-220).
  * int8 (DOT_PROD) vs float flavour is inferred from the size of the qweight arrays. */
 orc_model *orc_model_parse(const unsigned char *blob, int len, float lpc_gamma);
+void orc_model_set_end2end(orc_model *m, int on);   /* END2END of the generated nnet_data.h: LPC from reflection coefficients */
 void orc_model_free(orc_model *m);
 int  orc_model_is_int8(const orc_model *m);
 int  orc_model_nb_blocks(const orc_model *m, int which /*0 = GRU-A, 1 = GRU-B*/);

@@ -40,6 +40,8 @@ def lib():
     vp = C.c_void_p
     L.orc_model_parse.argtypes = [C.c_char_p, C.c_int, C.c_float]
     L.orc_model_parse.restype = vp
+    L.orc_model_set_end2end.argtypes = [vp, C.c_int]
+    L.orc_model_set_end2end.restype = None
     L.orc_model_free.argtypes = [vp]
     L.orc_model_is_int8.argtypes = [vp]
     L.orc_model_nb_blocks.argtypes = [vp, C.c_int]
@@ -81,12 +83,14 @@ def lib():
 
 
 class OracleModel:
-    def __init__(self, blob: bytes, lpc_gamma: float = 1.0):
+    def __init__(self, blob: bytes, lpc_gamma: float = 1.0, end2end: bool = False):
         self.L = lib()
         self._blob = C.create_string_buffer(blob, len(blob))
         self.p = self.L.orc_model_parse(self._blob, len(blob), lpc_gamma)
         if not self.p:
             raise ValueError("oracle: malformed weight blob")
+        if end2end:
+            self.L.orc_model_set_end2end(self.p, 1)
 
     def __del__(self):
         try:

@@ -443,3 +443,17 @@ def test_lpc_gamma_variant(blob_f32, hip_lib):
     with pytest.raises(api.LPCNetError):
         b.set_lpc_gamma(1.5)
     b.close()
+
+
+def test_end2end_variant(blob_f32, hip_lib):
+    """END2END models (src/lpcnet.c:56-80,107-108): LPC from the conditioning network's reflection coefficients"""
+    n, T = 3, 8
+    feats = feats_for([8200, 8201, 8202], T)
+    om = orc.OracleModel(blob_f32, lpc_gamma=0.95, end2end=True)
+    want = np.stack([om.new_state().synthesize(feats[s]) for s in range(n)])
+    b = api.LPCNetBatch(n, blob_f32)
+    b.set_end2end(True)
+    b.set_lpc_gamma(0.95)
+    got = np.concatenate([b.synthesize(feats[:, :3]), b.synthesize(feats[:, 3:])], axis=1)      # also across calls
+    assert np.array_equal(got, want)
+    b.close()

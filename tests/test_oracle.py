@@ -176,3 +176,13 @@ def test_lpc_gamma_variant_matches_reference(blob_f32):
     got = orc.OracleModel(blob_f32, lpc_gamma=0.9).new_state().synthesize(f)
     assert np.array_equal(got, want)
     assert not np.array_equal(got, orc.OracleModel(blob_f32).new_state().synthesize(f))
+
+
+@pytest.mark.skipif(not ref.available("ge"), reason="oracle/_ref END2END flavour not built (needs /root/reference)")
+def test_end2end_variant_matches_reference(blob_f32):
+    """END2END models (LPC from the network's reflection coefficients, src/lpcnet.c:56-80,107-108)"""
+    f = synth.make_features(4321, 40)
+    want = ref.RefLib("ge").new_state(blob_f32).synthesize(f)
+    got = orc.OracleModel(blob_f32, end2end=True).new_state().synthesize(f)
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got, orc.OracleModel(blob_f32).new_state().synthesize(f))
