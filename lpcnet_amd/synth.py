@@ -129,9 +129,11 @@ def _sparse_blocks(A, q):
 
 
 def make_model(seed=1234, flavour="float", shaped=True, densities=(0.05, 0.05, 0.2),
-               lpc_gamma=1.0, grub_density=1.0):
+               lpc_gamma=1.0, grub_density=1.0, off_grid=False):
     """Build the synthetic model.  The *same* seed gives the same network in both flavours
-    (weights are snapped to k/128); only the qweight element type / blocking differs."""
+    (weights are snapped to k/128); only the qweight element type / blocking differs.
+    off_grid=True (float flavour only) nudges the non-zero GRU weights off the k/128 grid, like a model trained
+    without quantisation."""
     assert flavour in ("float", "int8")
     rng = np.random.default_rng(seed)
     f32 = np.float32
@@ -166,6 +168,8 @@ def make_model(seed=1234, flavour="float", shaped=True, densities=(0.05, 0.05, 0
     m.add("gru_b_dense_feature_weights", Wb_in[N_A:], WEIGHT_TYPE_FLOAT)
     m.add("gru_b_dense_feature_bias", np.zeros(3 * N_B, f32), WEIGHT_TYPE_FLOAT)
     W0, W, idx = _sparse_blocks(Wb_a, Qb_a)
+    if off_grid and flavour == "float":
+        W0 = (W0 * (1.0 + 1e-3 * np.sin(np.arange(W0.size) * 0.37)).astype(f32)).astype(f32)
     m.add("gru_b_weights", W0 if flavour == "float" else W, WEIGHT_TYPE_QWEIGHT)
     m.add("gru_b_weights_idx", idx, WEIGHT_TYPE_INT)
     Wb_rec, Qb_rec = _quantize_matrix(normal((N_B, 3 * N_B), 0.25))
@@ -223,6 +227,8 @@ def make_model(seed=1234, flavour="float", shaped=True, densities=(0.05, 0.05, 0
     A, QA = _quantize_matrix(A)
     W0, W, idx = _sparse_blocks(A, QA)
     m.add("sparse_gru_a_recurrent_weights_diag", np.concatenate(diag), WEIGHT_TYPE_FLOAT)
+    if off_grid and flavour == "float":
+        W0 = (W0 * (1.0 + 1e-3 * np.cos(np.arange(W0.size) * 0.23)).astype(f32)).astype(f32)
     m.add("sparse_gru_a_recurrent_weights", W0 if flavour == "float" else W, WEIGHT_TYPE_QWEIGHT)
     m.add("sparse_gru_a_recurrent_weights_idx", idx, WEIGHT_TYPE_INT)
     subias_a = bias_a.copy()

@@ -59,6 +59,8 @@ def test_reset_seeds_rng_like_reference(hip_lib, golden):
 def test_check_model_accepts_and_rejects(blob_f32, blob_i8):
     rc, info = api.check_model(blob_f32)
     assert rc == 0 and info[:3] == [0, 1382, 576] and info[5] == 0 and 0 < info[3] <= 40
+    rc, info = api.check_model(synth.blob_bytes(synth.make_model(off_grid=True)))                 # weights off the k/128 grid
+    assert rc == 0 and info[:3] == [0, 1382, 576] and info[5] == 0 and 0 < info[3] <= 40
     rc, info = api.check_model(blob_i8)
     assert rc == 0 and info[:3] == [1, 1382, 576] and info[5] == 0 and 0 < info[3] <= 64      # int8 packing self-check
     assert api.check_model(blob_f32[:-64])[0] == -1                 # last record truncated

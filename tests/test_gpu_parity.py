@@ -457,3 +457,25 @@ def test_end2end_variant(blob_f32, hip_lib):
     got = np.concatenate([b.synthesize(feats[:, :3]), b.synthesize(feats[:, 3:])], axis=1)      # also across calls
     assert np.array_equal(got, want)
     b.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(grub_density=0.4), dict(densities=(0.07, 0.07, 0.25))], ids=["default", "sparseB", "denseA"])
+def test_off_grid_float_model(kw, hip_lib):
+    """float blobs whose GRU weights are NOT multiples of 1/128 (a model trained without quantisation; the synthetic
+    default and the int8 flavour sit on that grid): arbitrary float weights, same bar -- bit-exact against the oracle."""
+    blob = synth.blob_bytes(synth.make_model(off_grid=True, **kw))
+    rc, info = api.check_model(blob)
+    assert rc == 0 and info[0] == 0
+    n, T = 7, 9
+    feats = feats_for(range(2400, 2400 + n), T)
+    want, states = oracle_run(blob, feats)
+    for S in (1, 2, 4):
+        b = api.LPCNetBatch(n, blob)
+        b.streams_per_workgroup = S
+        got = b.synthesize(feats)
+        assert np.array_equal(got, want), (kw, S)
+        for s in (0, n - 1):
+            st = b.get_state(s)
+            _, _, ga, gb = states[s].nnet_state()
+            assert np.array_equal(np.array(st.gru_a, np.float32), ga) and np.array_equal(np.array(st.gru_b, np.float32), gb)
+        b.close()
