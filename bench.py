@@ -42,6 +42,8 @@ LDS_OPERAND_BYTES_PER_SAMPLE_I8 = 96432 # int8 GRU-A 59 544 + int8 GRU-B 21 912 
 PEAK_FP32_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector peak
 PEAK_HBM_GBS = 8000.0
 PEAK_LDS_TBS = 150.0
+MEASURED_FP32_MUL_ADD_TFLOPS = 58.9      # tools/ubench/peaks.hip on this box (profiles/r01_roofline_measured.json): separately
+                                        # rounded multiply + add, no FMA, no packed math -- all the PARITY arithmetic may use
 
 
 def _cpu_worker(args):
@@ -222,7 +224,9 @@ def main():
                          "note": "algorithmic operand bytes (each weight/table entry once per stream-sample); the engine keeps "
                                  "GRU-A weights in VGPRs and shares every LDS read among the workgroup's streams, so realised LDS bytes are lower",
                          "valu_fp32": {"achieved_TFLOPs": achieved_tflops, "peak_TFLOPs": PEAK_FP32_TFLOPS,
-                                       "frac": achieved_tflops / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE},
+                                       "frac": achieved_tflops / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE,
+                                       "measured_mul_add_no_fma_TFLOPs": MEASURED_FP32_MUL_ADD_TFLOPS,
+                                       "frac_of_measured_no_fma": achieved_tflops / MEASURED_FP32_MUL_ADD_TFLOPS},
                          "hbm": {"achieved_GBs": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS}},
         }
