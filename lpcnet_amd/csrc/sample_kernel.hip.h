@@ -571,11 +571,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             // gather sum in the reference's order ((cond + sig) + pred) + exc (src/nnet.c:431-440,
             // :487-489).  Candidate rows park the gathered input in sm_inh for the gate stage.  The
             // value is parked in the row's own sm_pre cell until the row becomes the running one.
-            // The gather-independent half of a start value (bias + diag*h and the frame condition) can be read and
-            // formed before the gathered rows -- or even the indices -- exist.  The int8 kernel has the registers to
-            // do that for all three slots while it waits (PRE_ROWS); the fp32 kernel forms it in place.
-            constexpr bool PRE_ROWS = I8;
-            float pre_b[PRE_ROWS ? 3 : 1][S] = {}, pre_c[PRE_ROWS ? 3 : 1][S] = {};
+            // The gather-independent half of a start value (bias + diag*h and the frame condition) is read and formed
+            // for all three slots before the wave waits for the indices / the gathered rows.
+            float pre_b[3][S] = {}, pre_c[3][S] = {};
             auto row_pre = [&](const int k, const int slot) {
                 int r = row[k];
                 LPCN_REMAT_V(r);
@@ -589,9 +587,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 }
             };
             auto row_init = [&](const int k, const int set, const bool to_acc, const bool park = true) {
-                if constexpr (!PRE_ROWS) row_pre(k, 0);
-                constexpr int dummy = 0; (void)dummy;
-                const int slot = PRE_ROWS ? k : 0;
+                const int slot = k;
                 int r = row[k];
                 LPCN_REMAT_V(r);
                 const bool live_row = r >= 0;
@@ -642,7 +638,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             const int jend = skip2 ? b2 : b3;
             const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR) ? 1 : 0);
             if (jmode == 0) {
-                if constexpr (PRE_ROWS) { row_pre(0, 0); row_pre(1, 1); row_pre(2, 2); }
+                row_pre(0, 0); row_pre(1, 1); row_pre(2, 2);
                 wait_indices();
                 load_indices();
                 gather(1, 0);
@@ -692,7 +688,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
 #pragma unroll
             for (int j = 0; j < JG && j < NW; ++j) item(j);  // (no wave ends before JG: jmode needs b1 >= JSTAR, others just fall through)
             if (jmode) {                                     // between two fully unrolled halves
-                if constexpr (PRE_ROWS) { row_pre(1, 1); row_pre(2, 2); }
+                row_pre(1, 1); row_pre(2, 2);
                 wait_indices();
                 load_indices();
                 gather(1, 0);
