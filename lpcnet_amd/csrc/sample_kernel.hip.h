@@ -658,7 +658,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     if constexpr (I8) acc[s] = acc[s] * QS;
                 }
             }
-            if (tid0 >= 256) __builtin_amdgcn_s_setprio(2);    // the younger wave of each SIMD pair sees its gather last: let it catch up
+            // issue priority for the part of GRU-A that everybody waits for: int8 -- the younger wave of each SIMD pair sees
+            // its gather last; fp32 -- the wave that still has a whole candidate slot in front of it (jmode)
+            if (I8 ? tid0 >= 256 : jmode != 0) __builtin_amdgcn_s_setprio(2);
             LPCN_PROF(10);     // gather issue + (light waves) wait + start values
 #pragma unroll
             for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
