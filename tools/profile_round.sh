@@ -9,6 +9,7 @@ OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 timeout 300 python bench.py --int8 --no-cpu-baseline > $OUT/bench_i8.json 2> $OUT/bench_i8.err
+timeout 300 python bench.py --streams 1 --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err      # BASELINE config 1
 for fl in f32 i8; do
   flag=""; [ $fl = i8 ] && flag="--int8"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1

@@ -44,4 +44,7 @@ for fl, suffix in (("f32", ""), ("i8", "_int8")):
                        "launch": "1024 streams x 25 frames x 160 samples = 4 096 000 output samples",
                        "command": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace)"},
                       open(os.path.join(DST, f"{RND}_hbm_traffic{suffix}.json"), "w"), indent=1)
+b = os.path.join(SRC, "bench_single.json")
+if os.path.exists(b) and os.path.getsize(b):
+    shutil.copy(b, os.path.join(DST, f"{RND}_bench_single_stream.json"))
 print(sorted(os.listdir(DST)))
