@@ -228,6 +228,25 @@ extern "C" int lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma)
 }
 
 // ------------------------------------------------------------------------------------ batches --
+// Streams per workgroup: one workgroup occupies a CU, so a batch runs in ceil(workgroups / CUs) rounds; a round with S
+// interleaved streams costs step[S] (measured us per sample step, tests/tools/gpu_sweep.py).  Pick the cheapest.
+static int auto_streams_per_wg(const lpcn_engine *e, int n)
+{
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    static const float step_f32[3] = {6.5f, 7.6f, 9.9f}, step_i8[3] = {4.4f, 5.5f, 7.3f};
+    const float *step = e->is_int8 ? step_i8 : step_f32;
+    int best = 1;
+    float best_t = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const int S = 1 << k, wgs = (n + S - 1) / S, rounds = (wgs + cus - 1) / cus;
+        const float t = rounds * step[k];
+        if (k == 0 || t < best_t) { best = S; best_t = t; }
+    }
+    return best;
+}
+
 extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n, int max_chunk)
 {
     *out = nullptr;
@@ -235,8 +254,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
     HIP_TRY(hipSetDevice(e->device));
     lpcn_batch_dev *b = new lpcn_batch_dev();
     b->e = e; b->n = n; b->max_chunk = max_chunk;
-    b->S = n >= 1024 ? 4 : (n >= 512 ? 2 : 1);          // fill 256 CUs first, then interleave
-    if (n >= 4 && n < 512) b->S = 1;
+    b->S = auto_streams_per_wg(e, n);
     auto fail = [&](int code) { lpcn_batch_dev_destroy(b); return code; };
 #define AL(ptr, bytes) if (hipMalloc((void **)&ptr, (bytes)) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) failed", (size_t)(bytes)); return fail(LPCN_E_HIP); }
     AL(b->d_state, sizeof(lpcn_stream_state) * n);
@@ -315,7 +333,7 @@ extern "C" int lpcn_batch_dev_set_state(lpcn_batch_dev *b, int s, const lpcn_str
 extern "C" int lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b) { return b->S; }
 extern "C" int lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s)
 {
-    if (s == 0) s = b->n >= 1024 ? 4 : (b->n >= 512 ? 2 : 1);
+    if (s == 0) s = auto_streams_per_wg(b->e, b->n);
     if (s != 1 && s != 2 && s != 4) { snprintf(g_err, sizeof(g_err), "streams per workgroup must be 1, 2 or 4"); return LPCN_E_ARG; }
     b->S = s;
     return 0;
