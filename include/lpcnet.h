@@ -8,13 +8,19 @@
  * engine's scope and are not exported.
  *
  * Differences a caller can observe:
- *   - The trained model is never compiled in: lpcnet_load_model() must be called on every state
- *     before lpcnet_synthesize() (the reference behaves like this when built with
- *     -DUSE_WEIGHTS_FILE, src/lpcnet.c:192-196, src/lpcnet_demo.c:205-207).
- *   - Arithmetic follows the reference's generic-C float path bit for bit (not its AVX2/NEON
- *     approximations); only float ("DISABLE_DOT_PROD") blobs are accepted in this round.
+ *   - The trained model is never compiled in.  A state uses the blob given to lpcnet_load_model()
+ *     (the reference's -DUSE_WEIGHTS_FILE flow, src/lpcnet.c:192-196, src/lpcnet_demo.c:205-207); a
+ *     state without one -- lpcnet_create() alone, or an LPCNetDecState, which the reference can only
+ *     run on its compiled-in model (src/lpcnet_demo.c:176-188) -- uses the process-default model:
+ *     lpcnet_hip_set_default_model(), else the file $LPCNET_HIP_MODEL, else ./weights_blob.bin.
+ *     The decoder's VQ codebooks (the reference's generated ceps_codebooks.c) come from
+ *     lpcnet_hip_set_codebooks(), else $LPCNET_HIP_CODEBOOKS, else ./ceps_codebooks.bin.
+ *   - Arithmetic follows the reference's generic-C path bit for bit (not its AVX2/NEON
+ *     approximations): float ("DISABLE_DOT_PROD") blobs like its generic float build, int8
+ *     ("DOT_PROD") blobs like its generic int8 build; the flavour is detected from the blob.
  *   - All compute runs on a HIP device; there is no CPU fallback.  If no device is usable,
- *     lpcnet_load_model() returns -1 and lpcnet_hip_last_error() says why.
+ *     lpcnet_load_model() returns -1 and lpcnet_hip_last_error() says why; entry points that return
+ *     void in the reference abort with a message on an unrecoverable device error.
  */
 #ifndef LPCNET_H_
 #define LPCNET_H_
@@ -54,7 +60,8 @@ LPCNET_EXPORT int lpcnet_get_size(void);                                        
 LPCNET_EXPORT int lpcnet_init(LPCNetState *st);                                    /* :169, returns 0 */
 LPCNET_EXPORT LPCNetState *lpcnet_create(void);                                    /* :174 */
 LPCNET_EXPORT void lpcnet_destroy(LPCNetState *st);                                /* :179 */
-/* one frame-network step on features[0..19] followed by N (<=160) output samples (:188) */
+/* one frame-network step on features[0..19] followed by N output samples (:188; any N > 0 like the reference,
+ * N <= 160 is the single-launch fast path) */
 LPCNET_EXPORT void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N);
 /* bind a "DNNw" weight blob; 0 on success, -1 on a malformed blob or missing device (:214).
  * Unlike the reference the blob is copied to the device and need not outlive the state. */
@@ -84,10 +91,18 @@ LPCNET_EXPORT const char *lpcnet_hip_last_error(void);
 /* install the VQ codebooks used by lpcnet_decode (the reference compiles them in from
  * ceps_codebooks.c, a generated file that is not part of its tree): cb1..3 [1024][17], diff4 [4096][18] */
 LPCNET_EXPORT void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4);
+/* process-default model for states that never saw lpcnet_load_model() (see the header comment); the blob is copied.
+ * 0 on success, -1 on a malformed blob or missing device. */
+LPCNET_EXPORT int lpcnet_hip_set_default_model(const unsigned char *data, int len);
+/* lpcnet_load_model() for a decoder state (LPCNetDecState is opaque in the reference and has no model entry point) */
+LPCNET_EXPORT int lpcnet_hip_decoder_load_model(LPCNetDecState *st, const unsigned char *data, int len);
+/* HIP device used by the single-stream API for models bound from now on (default: $LPCNET_HIP_DEVICE, else 0) */
+LPCNET_EXPORT int lpcnet_hip_set_device(int device);
 /* host-only blob validation (no GPU needed): 0 = loadable (float or int8 flavour), -1 = malformed.
  * info (may be NULL) receives {is_int8, GRU-A blocks, GRU-B blocks, items/lane, padded GRU-B blocks, selftest} */
 LPCNET_EXPORT int lpcnet_hip_check_model(const unsigned char *data, int len, int *info);
-/* release every device resource held for the single-stream API (optional, e.g. before exit) */
+/* release every device resource held for the single-stream API (optional, e.g. before exit); states stay bound and
+ * re-create the device side at their next call */
 LPCNET_EXPORT void lpcnet_hip_shutdown(void);
 
 #ifdef __cplusplus

@@ -22,6 +22,14 @@ typedef struct LPCNetBatch LPCNetBatch;
 
 /* n_streams independent synthesis states on HIP device `device`; NULL on failure. */
 LPCNET_EXPORT LPCNetBatch *lpcnet_batch_create(int n_streams, int device);
+/* The same, sharded over several HIP devices of one node: device k of `devices[0..n_devices)` owns a
+ * contiguous block of streams (sizes differ by at most one), with its own copy of the model, its own device buffers
+ * and HIP stream; host-pointer calls (synthesize, decode) run one host thread per shard concurrently and involve no
+ * communication between devices.  A device may be listed more than once (several shards on one GPU). */
+LPCNET_EXPORT LPCNetBatch *lpcnet_batch_create_sharded(int n_streams, const int *devices, int n_devices);
+LPCNET_EXPORT int lpcnet_batch_shards(const LPCNetBatch *b);
+/* block of streams [first, first+count) and device of one shard (any output may be NULL) */
+LPCNET_EXPORT int lpcnet_batch_shard_info(const LPCNetBatch *b, int shard, int *first, int *count, int *device);
 LPCNET_EXPORT void lpcnet_batch_destroy(LPCNetBatch *b);
 LPCNET_EXPORT int lpcnet_batch_streams(const LPCNetBatch *b);
 /* like lpcnet_load_model(): 0 or -1.  The blob is copied; it may be freed afterwards. */
@@ -37,6 +45,11 @@ LPCNET_EXPORT int lpcnet_batch_synthesize(LPCNetBatch *b, const float *features,
  * `hip_stream` (a hipStream_t; NULL = the batch's own stream).  lpcnet_batch_sync() waits. */
 LPCNET_EXPORT int lpcnet_batch_synthesize_device(LPCNetBatch *b, const float *d_features, int feat_stride, short *d_pcm,
                                                  int n_frames, void *hip_stream);
+/* device-pointer synthesis on ONE shard of a sharded batch: pointers are on that shard's device and cover only its
+ * `count` streams ([count][n_frames][feat_stride] / [count][n_frames*160]) */
+LPCNET_EXPORT int lpcnet_batch_synthesize_device_shard(LPCNetBatch *b, int shard, const float *d_features, int feat_stride,
+                                                       short *d_pcm, int n_frames, void *hip_stream);
+/* waits for everything enqueued for this batch, on whichever stream(s) it was enqueued */
 LPCNET_EXPORT int lpcnet_batch_sync(LPCNetBatch *b);
 /* Teacher-forced variant = lpcnet_synthesize_impl(..., preload) of the reference
  * (src/lpcnet.c:256-259,273): the first `preload` samples of every frame are read from pcm. */
@@ -75,6 +88,8 @@ LPCNET_EXPORT int lpcnet_batch_run_tail(LPCNetBatch *b, const float *cond_a, con
                                         short *pcm, int n_frames, int preload);
 LPCNET_EXPORT int lpcnet_batch_run_frames(LPCNetBatch *b, const float *features, int feat_stride,
                                           float *cond_a, float *cond_b, float *lpc, int n_frames);
+/* the engine's own correctly rounded 10^x of the LPC path (pow(10.f, x) of src/freq.c:317) evaluated on the device */
+LPCNET_EXPORT int lpcnet_hip_exp10_device(const float *x, double *out, int n);
 /* raw per-stream state record (layout = struct lpcn_stream_state in lpcnet_amd/csrc/lpcnet_engine.h) */
 LPCNET_EXPORT int lpcnet_batch_state_size(void);
 LPCNET_EXPORT int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out);

@@ -73,6 +73,14 @@ def load_library():
     L.lpcnet_hip_set_codebooks.argtypes = [_f32p] * 4
     L.lpcnet_hip_set_codebooks.restype = None
     L.lpcnet_hip_shutdown.restype = None
+    L.lpcnet_hip_set_default_model.argtypes = [C.c_char_p, C.c_int]
+    L.lpcnet_hip_decoder_load_model.argtypes = [vp, C.c_char_p, C.c_int]
+    L.lpcnet_hip_set_device.argtypes = [C.c_int]
+    L.lpcnet_batch_create_sharded.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.lpcnet_batch_create_sharded.restype = vp
+    L.lpcnet_batch_shards.argtypes = [vp]
+    L.lpcnet_batch_shard_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lpcnet_batch_synthesize_device_shard.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     L.lpcnet_hip_check_model.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     L.lpcnet_batch_create.argtypes = [C.c_int, C.c_int]
     L.lpcnet_batch_create.restype = vp
@@ -194,13 +202,14 @@ class LPCNetState:
 
 
 class LPCNetDecState:
-    def __init__(self, blob: bytes):
+    """lpcnet_decoder_create / lpcnet_decode; blob=None: the process-default model (what the reference's demo relies on)."""
+
+    def __init__(self, blob: bytes | None = None):
         self.L = load_library()
         self.p = self.L.lpcnet_decoder_create()
         self._blob = blob
-        # LPCNetDecState begins with its LPCNetState (reference: src/lpcnet_private.h:50-53)
-        if self.L.lpcnet_load_model(self.p, blob, len(blob)) != 0:
-            raise LPCNetError("lpcnet_load_model failed: " + last_error())
+        if blob is not None and self.L.lpcnet_hip_decoder_load_model(self.p, blob, len(blob)) != 0:
+            raise LPCNetError("lpcnet_hip_decoder_load_model failed: " + last_error())
 
     def decode(self, packet: np.ndarray) -> np.ndarray:
         pcm = np.zeros(LPCNET_PACKET_SAMPLES, np.int16)
@@ -215,17 +224,30 @@ class LPCNetDecState:
             pass
 
 
+def set_default_model(blob: bytes):
+    if load_library().lpcnet_hip_set_default_model(blob, len(blob)) != 0:
+        raise LPCNetError("lpcnet_hip_set_default_model failed: " + last_error())
+
+
+def shutdown():
+    load_library().lpcnet_hip_shutdown()
+
+
 def set_codebooks(cb1, cb2, cb3, cbd):
     load_library().lpcnet_hip_set_codebooks(*[np.ascontiguousarray(x, np.float32).reshape(-1) for x in (cb1, cb2, cb3, cbd)])
 
 
 class LPCNetBatch:
-    """n independent streams on one GPU (include/lpcnet_batch.h)."""
+    """n independent streams on one GPU, or sharded over `devices` (include/lpcnet_batch.h)."""
 
-    def __init__(self, n_streams: int, blob: bytes, device: int = 0):
+    def __init__(self, n_streams: int, blob: bytes, device: int = 0, devices=None):
         self.L = load_library()
         self.n = n_streams
-        self.p = self.L.lpcnet_batch_create(n_streams, device)
+        if devices is None:
+            self.p = self.L.lpcnet_batch_create(n_streams, device)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            self.p = self.L.lpcnet_batch_create_sharded(n_streams, arr, len(devices))
         if not self.p:
             raise LPCNetError("lpcnet_batch_create failed: " + last_error())
         if self.L.lpcnet_batch_load_model(self.p, blob, len(blob)) != 0:
@@ -270,6 +292,20 @@ class LPCNetBatch:
 
     def sync(self):
         self._chk(self.L.lpcnet_batch_sync(self.p), "sync")
+
+    @property
+    def shards(self):
+        """[(first, count, device)] of every shard"""
+        out = []
+        for k in range(self.L.lpcnet_batch_shards(self.p)):
+            a, b, c = C.c_int(), C.c_int(), C.c_int()
+            self._chk(self.L.lpcnet_batch_shard_info(self.p, k, C.byref(a), C.byref(b), C.byref(c)), "shard_info")
+            out.append((a.value, b.value, c.value))
+        return out
+
+    def synthesize_device_shard(self, shard: int, d_features_ptr: int, stride: int, d_pcm_ptr: int, n_frames: int, hip_stream: int = 0):
+        self._chk(self.L.lpcnet_batch_synthesize_device_shard(self.p, shard, d_features_ptr, stride, d_pcm_ptr, n_frames, hip_stream or None),
+                  "synthesize_device_shard")
 
     def set_lpc_gamma(self, gamma: float):
         self._chk(self.L.lpcnet_batch_set_lpc_gamma(self.p, gamma), "set_lpc_gamma")

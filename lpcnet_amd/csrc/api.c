@@ -6,8 +6,15 @@
  * by value (PLC snapshot / rollback, src/lpcnet_plc.c:216-231).  LPCNetState therefore stays a
  * self-contained POD: it carries the complete per-stream state plus an integer handle of the
  * model; device memory belongs to a process-global registry (one engine + one 1-stream device
- * batch per distinct blob).  Every lpcnet_synthesize() call uploads the POD state, runs one frame
- * on the device and downloads state + PCM.
+ * batch per distinct blob, created lazily on the device chosen with lpcnet_hip_set_device()).  The registry
+ * remembers the POD state it last downloaded: a lpcnet_synthesize() call whose state still equals that copy
+ * (the normal frame-after-frame case) skips the upload; the new state and the PCM come back in one pinned
+ * transfer with one synchronisation per frame.
+ *
+ * A state without an explicitly loaded model uses the process-default model, which mirrors the reference's
+ * compiled-in model: lpcnet_hip_set_default_model(), else the file named by $LPCNET_HIP_MODEL, else
+ * ./weights_blob.bin (the file name the reference's demo hard-codes, src/lpcnet_demo.c:113).  The same applies
+ * to the decoder's VQ codebooks ($LPCNET_HIP_CODEBOOKS, ./ceps_codebooks.bin).
  */
 #include <pthread.h>
 #include <math.h>
@@ -42,11 +49,19 @@ struct LPCNetDecState {
     float vq_mem[LPCN_NB_BANDS];
 };
 
-struct LPCNetBatch {
-    int n, device;
+/* A batch is one or more shards: contiguous blocks of streams, each on its own HIP device with its own engine,
+ * device buffers and stream (streams are independent, so shards never communicate). */
+#define LPCN_MAX_SHARDS 16
+typedef struct {
+    int first, count, device;
     lpcn_engine *engine;
     lpcn_batch_dev *dev;
     int cb_version;                   /* g_cb_version of the codebooks on the device (0 = none) */
+} batch_shard;
+
+struct LPCNetBatch {
+    int n, n_shards;
+    batch_shard sh[LPCN_MAX_SHARDS];
 };
 
 static __thread char tl_err[512];
@@ -60,18 +75,63 @@ static float *g_cb[4];
 static int g_cb_version;              /* bumped by every lpcnet_hip_set_codebooks: batches re-upload lazily */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
+static const size_t g_cb_count[4] = {1024 * 17, 1024 * 17, 1024 * 17, 4096 * 18};
+
+static int install_codebooks_locked(const float *const src[4])
+{
+    float *fresh[4] = {NULL, NULL, NULL, NULL};
+    for (int i = 0; i < 4; i++) {
+        fresh[i] = (float *)malloc(g_cb_count[i] * sizeof(float));
+        if (!fresh[i]) { for (int k = 0; k < i; k++) free(fresh[k]); return -1; }
+        memcpy(fresh[i], src[i], g_cb_count[i] * sizeof(float));
+    }
+    for (int i = 0; i < 4; i++) { free(g_cb[i]); g_cb[i] = fresh[i]; }
+    g_cb_version++;
+    return 0;
+}
+
 void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *cb3, const float *cbd)
 {
-    const float *src[4] = {cb1, cb2, cb3, cbd};
-    const size_t cnt[4] = {1024 * 17, 1024 * 17, 1024 * 17, 4096 * 18};
+    const float *const src[4] = {cb1, cb2, cb3, cbd};
     pthread_mutex_lock(&g_lock);
-    for (int i = 0; i < 4; i++) {
-        free(g_cb[i]);
-        g_cb[i] = (float *)malloc(cnt[i] * sizeof(float));
-        memcpy(g_cb[i], src[i], cnt[i] * sizeof(float));
-    }
-    g_cb_version++;
+    if (install_codebooks_locked(src) != 0) set_err("lpcnet_hip_set_codebooks: out of memory");
     pthread_mutex_unlock(&g_lock);
+}
+
+/* whole file into malloc'ed memory (NULL if absent / unreadable / empty) */
+static unsigned char *read_file(const char *path, long *len)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    unsigned char *buf = NULL;
+    long n = -1;
+    if (fseek(f, 0, SEEK_END) == 0 && (n = ftell(f)) > 0 && fseek(f, 0, SEEK_SET) == 0) {
+        buf = (unsigned char *)malloc((size_t)n);
+        if (buf && fread(buf, 1, (size_t)n, f) != (size_t)n) { free(buf); buf = NULL; }
+    }
+    fclose(f);
+    *len = n;
+    return buf;
+}
+
+/* Process-default codebooks (the reference compiles ceps_codebooks.c in): $LPCNET_HIP_CODEBOOKS, else ./ceps_codebooks.bin;
+ * raw little-endian float32: ceps_codebook1..3 [1024][17] each, then ceps_codebook_diff4 [4096][18]. */
+static void default_codebooks_locked(void)
+{
+    static int tried;
+    if (g_cb[0] || tried) return;
+    tried = 1;
+    const char *path = getenv("LPCNET_HIP_CODEBOOKS");
+    long len = 0;
+    unsigned char *buf = read_file(path && *path ? path : "ceps_codebooks.bin", &len);
+    if (!buf) return;
+    const size_t want = (g_cb_count[0] + g_cb_count[1] + g_cb_count[2] + g_cb_count[3]) * sizeof(float);
+    if ((size_t)len == want) {
+        const float *f = (const float *)buf;
+        const float *const src[4] = {f, f + g_cb_count[0], f + g_cb_count[0] + g_cb_count[1], f + g_cb_count[0] + g_cb_count[1] + g_cb_count[2]};
+        (void)install_codebooks_locked(src);
+    }
+    free(buf);
 }
 
 /* packet -> 4 feature vectors.  Follows src/lpcnet_dec.c:81-155 and src/common.c:37-65:
@@ -89,8 +149,10 @@ static void band_interp(float *x, const float *left, const float *right, int mod
         x[i] = mode == 0 ? .5f * (left[i] + right[i]) : (mode == 1 ? left[i] : right[i]);
 }
 
+/* (called with g_lock held: the codebooks may be replaced by another thread) */
 static int packet_to_features(float feat[4][NB_TOTAL_FEATURES], float *vq_mem, const unsigned char *buf)
 {
+    default_codebooks_locked();
     if (!g_cb[0]) return -1;
     int pos = 0;
     const int c0_id = (int)get_bits(buf, &pos, 7), main_pitch = (int)get_bits(buf, &pos, 6);
@@ -127,15 +189,25 @@ static int packet_to_features(float feat[4][NB_TOTAL_FEATURES], float *vq_mem, c
     return 0;
 }
 
-/* ---- model registry for the single-stream API ------------------------------------------------ */
+/* ---- model registry for the single-stream API ------------------------------------------------
+ * One slot per distinct weight blob (the registry keeps its own copy: dedupe compares the bytes, and a slot can
+ * rebuild its device side at any time).  Slots live until process exit; lpcnet_hip_shutdown() only releases the
+ * device resources, so a state bound before the shutdown simply re-creates them at its next call. */
 typedef struct {
     int used;
-    const unsigned char *blob; int len; uint64_t hash;
+    unsigned char *blob; int len; uint64_t hash;
     lpcn_engine *engine;
     lpcn_batch_dev *dev;              /* 1 stream */
+    int device;
+    int cache_valid;                  /* `cached` equals the device copy of the stream state */
+    lpcn_stream_state cached;
+    pthread_mutex_t run_lock;         /* one device round trip at a time per model */
 } registry_entry;
 #define MAX_MODELS 16
 static registry_entry g_reg[MAX_MODELS];
+static int g_device = -1;             /* device of the single-stream API: lpcnet_hip_set_device(), $LPCNET_HIP_DEVICE, else 0 */
+static int g_default_model = -1;      /* registry slot of the process-default model, -1 = not resolved yet */
+static int g_default_tried;
 
 static uint64_t fnv1a(const unsigned char *p, int n)
 {
@@ -144,39 +216,100 @@ static uint64_t fnv1a(const unsigned char *p, int n)
     return h;
 }
 
+static int single_stream_device(void)
+{
+    if (g_device >= 0) return g_device;
+    const char *e = getenv("LPCNET_HIP_DEVICE");
+    return (e && *e) ? atoi(e) : 0;
+}
+
+int lpcnet_hip_set_device(int device)
+{
+    if (device < 0) { set_err("lpcnet_hip_set_device: bad device"); return -1; }
+    pthread_mutex_lock(&g_lock);
+    g_device = device;
+    pthread_mutex_unlock(&g_lock);
+    return 0;
+}
+
+/* (g_lock held) device side of a slot, created on first use and after lpcnet_hip_shutdown() */
+static int registry_materialize(registry_entry *r)
+{
+    if (r->dev) return 0;
+    lpcn_model_host m;
+    if (lpcn_model_parse(&m, r->blob, r->len) != 0) { set_err("malformed or incomplete DNNw weight blob"); return -1; }
+    lpcn_engine *e = NULL;
+    lpcn_batch_dev *d = NULL;
+    const int device = single_stream_device();
+    int rc = lpcn_engine_create(&e, device, &m);
+    lpcn_model_release(&m);
+    if (rc) { take_engine_err(); return -1; }
+    rc = lpcn_batch_dev_create(&d, e, 1, 1);
+    if (rc) { take_engine_err(); lpcn_engine_destroy(e); return -1; }
+    r->engine = e; r->dev = d; r->device = device; r->cache_valid = 0;
+    return 0;
+}
+
+/* (g_lock held) slot of this blob, new or existing; -1 on a malformed blob / no device / table full */
 static int registry_bind(const unsigned char *blob, int len)
 {
     const uint64_t h = fnv1a(blob, len);
     int slot = -1;
     for (int i = 0; i < MAX_MODELS; i++) {
-        if (g_reg[i].used && g_reg[i].len == len && g_reg[i].hash == h) return i;
+        if (g_reg[i].used && g_reg[i].len == len && g_reg[i].hash == h && memcmp(g_reg[i].blob, blob, (size_t)len) == 0)
+            return registry_materialize(&g_reg[i]) == 0 ? i : -1;
         if (!g_reg[i].used && slot < 0) slot = i;
     }
     if (slot < 0) { set_err("too many distinct models bound through lpcnet_load_model"); return -1; }
-    lpcn_model_host m;
-    if (lpcn_model_parse(&m, blob, len) != 0) { set_err("malformed or incomplete DNNw weight blob"); return -1; }
-    lpcn_engine *e = NULL;
-    lpcn_batch_dev *d = NULL;
-    int rc = lpcn_engine_create(&e, 0, &m);
-    lpcn_model_release(&m);
-    if (rc) { take_engine_err(); return -1; }
-    rc = lpcn_batch_dev_create(&d, e, 1, 1);
-    if (rc) { take_engine_err(); lpcn_engine_destroy(e); return -1; }
-    g_reg[slot].used = 1; g_reg[slot].blob = blob; g_reg[slot].len = len; g_reg[slot].hash = h;
-    g_reg[slot].engine = e; g_reg[slot].dev = d;
+    registry_entry *r = &g_reg[slot];
+    memset(r, 0, sizeof(*r));
+    r->blob = (unsigned char *)malloc((size_t)len);
+    if (!r->blob) { set_err("out of memory"); return -1; }
+    memcpy(r->blob, blob, (size_t)len);
+    r->len = len; r->hash = h;
+    if (registry_materialize(r) != 0) { free(r->blob); r->blob = NULL; return -1; }
+    pthread_mutex_init(&r->run_lock, NULL);
+    r->used = 1;
     return slot;
 }
 
+/* Device resources of the single-stream API are released; bound states stay valid and re-create them on demand. */
 void lpcnet_hip_shutdown(void)
 {
     pthread_mutex_lock(&g_lock);
     for (int i = 0; i < MAX_MODELS; i++)
-        if (g_reg[i].used) {
+        if (g_reg[i].used && g_reg[i].dev) {
+            pthread_mutex_lock(&g_reg[i].run_lock);
             lpcn_batch_dev_destroy(g_reg[i].dev);
             lpcn_engine_destroy(g_reg[i].engine);
-            g_reg[i].used = 0;
+            g_reg[i].dev = NULL; g_reg[i].engine = NULL; g_reg[i].cache_valid = 0;
+            pthread_mutex_unlock(&g_reg[i].run_lock);
         }
     pthread_mutex_unlock(&g_lock);
+}
+
+int lpcnet_hip_set_default_model(const unsigned char *data, int len)
+{
+    if (!data || len <= 0) { set_err("lpcnet_hip_set_default_model: bad arguments"); return -1; }
+    pthread_mutex_lock(&g_lock);
+    const int id = registry_bind(data, len);
+    if (id >= 0) { g_default_model = id; g_default_tried = 1; }
+    pthread_mutex_unlock(&g_lock);
+    return id >= 0 ? 0 : -1;
+}
+
+/* (g_lock held) the process-default model: explicit, else $LPCNET_HIP_MODEL, else ./weights_blob.bin */
+static int default_model_locked(void)
+{
+    if (g_default_model >= 0 || g_default_tried) return g_default_model;
+    g_default_tried = 1;
+    const char *path = getenv("LPCNET_HIP_MODEL");
+    long len = 0;
+    unsigned char *buf = read_file(path && *path ? path : "weights_blob.bin", &len);
+    if (!buf) return -1;
+    if (len > 0 && len < 0x7FFFFFFF) g_default_model = registry_bind(buf, (int)len);
+    free(buf);
+    return g_default_model;
 }
 
 /* ---- single-stream API ------------------------------------------------------------------------ */
@@ -209,7 +342,7 @@ void lpcnet_reset(LPCNetState *st)
 int lpcnet_init(LPCNetState *st)
 {
     st->magic = LPCN_MAGIC;
-    st->model_id = -1;
+    st->model_id = -1;                /* resolved to the process-default model at first use (the reference binds its compiled-in model here) */
     lpcnet_reset(st);
     return 0;
 }
@@ -230,24 +363,60 @@ int lpcnet_load_model(LPCNetState *st, const unsigned char *data, int len)
     const int id = registry_bind(data, len);
     pthread_mutex_unlock(&g_lock);
     if (id < 0) return -1;
+    st->magic = LPCN_MAGIC;
     st->model_id = id;
     return 0;
 }
 
-static lpcn_batch_dev *bound_device(const LPCNetState *st, const char *who)
+/* The reference has no public way to give an LPCNetDecState a model other than its compiled-in one
+ * (src/lpcnet.c:284-290: lpcnet_decoder_init -> lpcnet_init); this is the explicit form for weight-file users. */
+int lpcnet_hip_decoder_load_model(LPCNetDecState *st, const unsigned char *data, int len)
 {
-    if (st->magic != LPCN_MAGIC || st->model_id < 0 || st->model_id >= MAX_MODELS || !g_reg[st->model_id].used) {
-        fprintf(stderr, "%s: no model bound to this state (call lpcnet_load_model first); "
-                        "the HIP engine has no built-in model and no CPU fallback\n", who);
+    if (!st) { set_err("lpcnet_hip_decoder_load_model: bad arguments"); return -1; }
+    return lpcnet_load_model(&st->lpcnet_state, data, len);
+}
+
+/* The registry slot this state runs on, locked for one device round trip (unlock with release_entry). */
+static registry_entry *acquire_entry(LPCNetState *st, const char *who)
+{
+    pthread_mutex_lock(&g_lock);
+    int id = (st->magic == LPCN_MAGIC) ? st->model_id : -1;
+    if (id < 0 || id >= MAX_MODELS || !g_reg[id].used) {
+        id = default_model_locked();
+        if (id >= 0 && st->magic == LPCN_MAGIC) st->model_id = id;
+    }
+    if (id < 0 || registry_materialize(&g_reg[id]) != 0) {
+        pthread_mutex_unlock(&g_lock);
+        fprintf(stderr, "%s: no model bound to this state and no default model (lpcnet_load_model, lpcnet_hip_set_default_model, "
+                        "$LPCNET_HIP_MODEL or ./weights_blob.bin): %s; the HIP engine has no built-in model and no CPU fallback\n",
+                who, tl_err[0] ? tl_err : "none found");
         abort();
     }
-    return g_reg[st->model_id].dev;
+    registry_entry *r = &g_reg[id];
+    pthread_mutex_lock(&r->run_lock);
+    pthread_mutex_unlock(&g_lock);
+    return r;
 }
+static void release_entry(registry_entry *r) { pthread_mutex_unlock(&r->run_lock); }
 
 static void device_failure(const char *who)
 {
     fprintf(stderr, "%s: device failure: %s\n", who, lpcn_last_error());
     abort();
+}
+
+/* upload the caller's POD state unless it is the copy the device already holds */
+static int push_state(registry_entry *r, const lpcn_stream_state *s)
+{
+    if (r->cache_valid && memcmp(&r->cached, s, sizeof(*s)) == 0) return 0;
+    r->cache_valid = 0;
+    return lpcn_batch_dev_set_state(r->dev, 0, s);
+}
+static int pull_state(registry_entry *r, lpcn_stream_state *s)
+{
+    int rc = lpcn_batch_dev_get_state(r->dev, 0, s);
+    if (!rc) { r->cached = *s; r->cache_valid = 1; }
+    return rc;
 }
 
 /* ---- the reference's internal entry points (src/lpcnet_private.h:125-132), which src/lpcnet_plc.c links to ---- */
@@ -265,13 +434,13 @@ void lpcnet_reset_signal(LPCNetState *st)
 /* src/lpcnet.c:82-120: one step of the 100 Hz network; products go to the caller's arrays */
 void run_frame_network(LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features)
 {
-    lpcn_batch_dev *d = bound_device(st, "run_frame_network");
+    registry_entry *r = acquire_entry(st, "run_frame_network");
     float lpc_new[LPCN_LPC_ORDER];      /* `lpc` may point into st->s, which the state download overwrites */
-    pthread_mutex_lock(&g_lock);
-    int rc = lpcn_batch_dev_set_state(d, 0, &st->s);
-    if (!rc) rc = lpcn_batch_dev_run_frames_host(d, features, NB_FEATURES, gru_a_condition, gru_b_condition, lpc_new, 1);
-    if (!rc) rc = lpcn_batch_dev_get_state(d, 0, &st->s);
-    pthread_mutex_unlock(&g_lock);
+    int rc = push_state(r, &st->s);
+    r->cache_valid = 0;
+    if (!rc) rc = lpcn_batch_dev_run_frames_host(r->dev, features, NB_FEATURES, gru_a_condition, gru_b_condition, lpc_new, 1);
+    if (!rc) rc = pull_state(r, &st->s);
+    release_entry(r);
     if (rc) device_failure("run_frame_network");
     memcpy(lpc, lpc_new, sizeof(lpc_new));
 }
@@ -298,26 +467,31 @@ void run_frame_network_flush(LPCNetState *st)
 }
 
 /* src/lpcnet.c:235-271: N samples from the products held in the state; the first `preload` samples of
- * `output` are imposed on the synthesis filter (teacher forcing) instead of being written */
+ * `output` are imposed on the synthesis filter (teacher forcing) instead of being written.  Any N: the
+ * sample loop does not care where a call ends, so N > 160 runs as consecutive pieces of <= 160 samples. */
 void lpcnet_synthesize_tail_impl(LPCNetState *st, short *output, int N, int preload)
 {
     if (N <= 0) return;
-    lpcn_batch_dev *d = bound_device(st, "lpcnet_synthesize_tail_impl");
-    if (N > LPCN_FRAME_SIZE || preload < 0 || preload > N) {
-        fprintf(stderr, "lpcnet_synthesize_tail_impl: N=%d preload=%d outside 1..%d / 0..N\n", N, preload, LPCN_FRAME_SIZE);
+    if (preload < 0 || preload > N) {
+        fprintf(stderr, "lpcnet_synthesize_tail_impl: preload=%d outside 0..N=%d\n", preload, N);
         abort();
     }
-    short frame[LPCN_FRAME_SIZE] = {0};
-    memcpy(frame, output, sizeof(short) * (size_t)preload);
-    pthread_mutex_lock(&g_lock);
-    int rc = lpcn_batch_dev_set_state(d, 0, &st->s);
-    if (!rc) rc = lpcn_batch_dev_set_frame_len(d, N);
-    if (!rc) rc = lpcn_batch_dev_run_tail_host(d, st->gru_a_condition, st->gru_b_condition, st->s.lpc, frame, 1, preload);
-    if (!rc) rc = lpcn_batch_dev_get_state(d, 0, &st->s);
-    pthread_mutex_unlock(&g_lock);
+    registry_entry *r = acquire_entry(st, "lpcnet_synthesize_tail_impl");
+    int rc = push_state(r, &st->s);
+    r->cache_valid = 0;
+    for (int done = 0; !rc && done < N; done += LPCN_FRAME_SIZE) {
+        const int n = N - done < LPCN_FRAME_SIZE ? N - done : LPCN_FRAME_SIZE;
+        const int pre = preload - done < 0 ? 0 : (preload - done > n ? n : preload - done);
+        short frame[LPCN_FRAME_SIZE] = {0};
+        memcpy(frame, output + done, sizeof(short) * (size_t)pre);
+        rc = lpcn_batch_dev_set_frame_len(r->dev, n);
+        if (!rc) rc = lpcn_batch_dev_run_tail_host(r->dev, st->gru_a_condition, st->gru_b_condition, st->s.lpc, frame, 1, pre);
+        /* live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243) */
+        if (!rc) memcpy(output + done, frame, sizeof(short) * (size_t)n);
+    }
+    if (!rc) rc = pull_state(r, &st->s);
+    release_entry(r);
     if (rc) device_failure("lpcnet_synthesize_tail_impl");
-    /* live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243) */
-    memcpy(output, frame, sizeof(short) * (size_t)N);
 }
 
 /* src/lpcnet.c:273-277 */
@@ -327,25 +501,21 @@ void lpcnet_synthesize_impl(LPCNetState *st, const float *features, short *outpu
     lpcnet_synthesize_tail_impl(st, output, N, preload);
 }
 
-/* src/lpcnet.c:279-281.  (One fused device pass: frame kernels and sample kernel back to back; equals
- * lpcnet_synthesize_impl(..., 0) bit for bit, tests/test_gpu_parity.py.) */
+/* src/lpcnet.c:279-281.  N <= 160 (every caller in the reference): one fused device pass -- frame kernels and sample
+ * kernel back to back, one synchronisation; bit-identical to lpcnet_synthesize_impl(..., 0) (tests/test_gpu_parity.py).
+ * N > 160: the reference runs the frame network once and then N samples; so does the two-step form. */
 void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)
 {
     if (N <= 0) return;
-    lpcn_batch_dev *d = bound_device(st, "lpcnet_synthesize");
-    if (N > LPCN_FRAME_SIZE) {
-        fprintf(stderr, "lpcnet_synthesize: N=%d > %d samples per call is not supported by the HIP engine\n", N, LPCN_FRAME_SIZE);
-        abort();
-    }
-    pthread_mutex_lock(&g_lock);
-    short frame[LPCN_FRAME_SIZE];
-    int rc = lpcn_batch_dev_set_state(d, 0, &st->s);
-    if (!rc) rc = lpcn_batch_dev_set_frame_len(d, N);
-    if (!rc) rc = lpcn_batch_dev_run_host(d, features, NB_FEATURES, frame, 1, 0);
-    if (!rc) rc = lpcn_batch_dev_get_state(d, 0, &st->s);
-    pthread_mutex_unlock(&g_lock);
+    if (N > LPCN_FRAME_SIZE) { lpcnet_synthesize_impl(st, features, output, N, 0); return; }
+    registry_entry *r = acquire_entry(st, "lpcnet_synthesize");
+    const int fresh = !(r->cache_valid && memcmp(&r->cached, &st->s, sizeof(st->s)) == 0);
+    r->cache_valid = 0;
+    int rc = lpcn_batch_dev_set_frame_len(r->dev, N);
+    if (!rc) rc = lpcn_batch_dev_run_single(r->dev, fresh ? &st->s : NULL, features, output, &st->s);
+    if (!rc) { r->cached = st->s; r->cache_valid = 1; }
+    release_entry(r);
     if (rc) device_failure("lpcnet_synthesize");
-    memcpy(output, frame, sizeof(short) * (size_t)N);
 }
 
 /* ---- decoder ----------------------------------------------------------------------------------- */
@@ -370,8 +540,11 @@ void lpcnet_decoder_destroy(LPCNetDecState *st) { free(st); }
 int lpcnet_decode(LPCNetDecState *st, const unsigned char *buf, short *pcm)
 {
     float feat[4][NB_TOTAL_FEATURES];
-    if (packet_to_features(feat, st->vq_mem, buf) != 0) {
-        set_err("lpcnet_decode: no VQ codebooks installed (lpcnet_hip_set_codebooks)");
+    pthread_mutex_lock(&g_lock);
+    const int rc = packet_to_features(feat, st->vq_mem, buf);
+    pthread_mutex_unlock(&g_lock);
+    if (rc != 0) {
+        set_err("lpcnet_decode: no VQ codebooks installed (lpcnet_hip_set_codebooks, $LPCNET_HIP_CODEBOOKS or ./ceps_codebooks.bin)");
         return -1;
     }
     for (int k = 0; k < 4; k++)
@@ -380,83 +553,191 @@ int lpcnet_decode(LPCNetDecState *st, const unsigned char *buf, short *pcm)
 }
 
 /* ---- batch API ----------------------------------------------------------------------------------- */
+/* contiguous block partition: shard k of K gets n/K streams, the first n%K shards one more */
+static void shard_partition(int n, int k, int K, int *first, int *count)
+{
+    const int base = n / K, extra = n % K;
+    *count = base + (k < extra ? 1 : 0);
+    *first = k * base + (k < extra ? k : extra);
+}
+
+LPCNetBatch *lpcnet_batch_create_sharded(int n_streams, const int *devices, int n_devices)
+{
+    if (n_streams <= 0 || !devices || n_devices <= 0 || n_devices > LPCN_MAX_SHARDS) { set_err("lpcnet_batch_create_sharded: bad arguments"); return NULL; }
+    for (int k = 0; k < n_devices; k++) if (devices[k] < 0) { set_err("lpcnet_batch_create_sharded: bad device"); return NULL; }
+    LPCNetBatch *b = (LPCNetBatch *)calloc(1, sizeof(*b));
+    if (!b) return NULL;
+    b->n = n_streams;
+    for (int k = 0; k < n_devices; k++) {
+        int first, count;
+        shard_partition(n_streams, k, n_devices, &first, &count);
+        if (count == 0) continue;          /* more devices than streams */
+        batch_shard *s = &b->sh[b->n_shards++];
+        s->first = first; s->count = count; s->device = devices[k];
+    }
+    return b;
+}
+
 LPCNetBatch *lpcnet_batch_create(int n_streams, int device)
 {
     if (n_streams <= 0 || device < 0) { set_err("lpcnet_batch_create: bad arguments"); return NULL; }
-    LPCNetBatch *b = (LPCNetBatch *)calloc(1, sizeof(*b));
-    if (!b) return NULL;
-    b->n = n_streams; b->device = device;
-    return b;
+    return lpcnet_batch_create_sharded(n_streams, &device, 1);
 }
 
 void lpcnet_batch_destroy(LPCNetBatch *b)
 {
     if (!b) return;
-    if (b->dev) lpcn_batch_dev_destroy(b->dev);
-    if (b->engine) lpcn_engine_destroy(b->engine);
+    for (int k = 0; k < b->n_shards; k++) {
+        if (b->sh[k].dev) lpcn_batch_dev_destroy(b->sh[k].dev);
+        if (b->sh[k].engine) lpcn_engine_destroy(b->sh[k].engine);
+    }
     free(b);
 }
 
 int lpcnet_batch_streams(const LPCNetBatch *b) { return b->n; }
+int lpcnet_batch_shards(const LPCNetBatch *b) { return b ? b->n_shards : 0; }
+
+int lpcnet_batch_shard_info(const LPCNetBatch *b, int shard, int *first, int *count, int *device)
+{
+    if (!b || shard < 0 || shard >= b->n_shards) { set_err("shard index"); return LPCN_E_ARG; }
+    if (first) *first = b->sh[shard].first;
+    if (count) *count = b->sh[shard].count;
+    if (device) *device = b->sh[shard].device;
+    return 0;
+}
 
 #define BATCH_CHUNK_FRAMES 100       /* frame products are staged per chunk: 100 frames = 1 s of audio */
 
 int lpcnet_batch_load_model(LPCNetBatch *b, const unsigned char *data, int len)
 {
     lpcn_model_host m;
+    if (!b) { set_err("lpcnet_batch_load_model: bad arguments"); return -1; }
     if (lpcn_model_parse(&m, data, len) != 0) { set_err("malformed or incomplete DNNw weight blob"); return -1; }
-    lpcn_engine *e = NULL;
-    lpcn_batch_dev *d = NULL;
-    int rc = lpcn_engine_create(&e, b->device, &m);
+    lpcn_engine *e[LPCN_MAX_SHARDS] = {0};
+    lpcn_batch_dev *d[LPCN_MAX_SHARDS] = {0};
+    int rc = 0;
+    for (int k = 0; k < b->n_shards && !rc; k++) {          /* the model is replicated on every shard's device */
+        rc = lpcn_engine_create(&e[k], b->sh[k].device, &m);
+        if (!rc) rc = lpcn_batch_dev_create(&d[k], e[k], b->sh[k].count, BATCH_CHUNK_FRAMES);
+    }
     lpcn_model_release(&m);
-    if (rc) { take_engine_err(); return -1; }
-    rc = lpcn_batch_dev_create(&d, e, b->n, BATCH_CHUNK_FRAMES);
-    if (rc) { take_engine_err(); lpcn_engine_destroy(e); return -1; }
-    if (b->dev) lpcn_batch_dev_destroy(b->dev);
-    if (b->engine) lpcn_engine_destroy(b->engine);
-    b->engine = e; b->dev = d;
+    if (rc) {
+        take_engine_err();
+        for (int k = 0; k < b->n_shards; k++) { if (d[k]) lpcn_batch_dev_destroy(d[k]); if (e[k]) lpcn_engine_destroy(e[k]); }
+        return -1;
+    }
+    for (int k = 0; k < b->n_shards; k++) {
+        if (b->sh[k].dev) lpcn_batch_dev_destroy(b->sh[k].dev);
+        if (b->sh[k].engine) lpcn_engine_destroy(b->sh[k].engine);
+        b->sh[k].engine = e[k]; b->sh[k].dev = d[k]; b->sh[k].cb_version = 0;
+    }
     return 0;
 }
 
-#define NEED_MODEL(b) do { if (!(b) || !(b)->dev) { set_err("batch has no model (lpcnet_batch_load_model)"); return LPCN_E_MODEL; } } while (0)
+#define NEED_MODEL(b) do { if (!(b) || !(b)->n_shards || !(b)->sh[0].dev) { set_err("batch has no model (lpcnet_batch_load_model)"); return LPCN_E_MODEL; } } while (0)
 #define FWD(call) do { int rc_ = (call); if (rc_) take_engine_err(); return rc_; } while (0)
+#define NEED_ONE_SHARD(b, what) do { if ((b)->n_shards != 1) { set_err(what ": device pointers belong to one device; use the _shard form on a sharded batch"); return LPCN_E_ARG; } } while (0)
+
+/* ---- one host thread per shard: the shards of a host-pointer call run concurrently, each on its own
+ * device and stream; with a single shard the work runs on the calling thread. */
+typedef struct {
+    LPCNetBatch *b; int shard;
+    int kind;                                     /* 0 synthesize(preload), 1 decode */
+    const float *features; int feat_stride; short *pcm; int n_frames, preload;
+    const unsigned char *packets; int n_packets;
+    int rc; char err[256];
+} shard_job;
+
+static void *shard_worker(void *arg)
+{
+    shard_job *j = (shard_job *)arg;
+    batch_shard *s = &j->b->sh[j->shard];
+    if (j->kind == 0)
+        j->rc = lpcn_batch_dev_run_host(s->dev, j->features + (size_t)s->first * j->n_frames * j->feat_stride, j->feat_stride,
+                                        j->pcm + (size_t)s->first * j->n_frames * LPCN_FRAME_SIZE, j->n_frames, j->preload);
+    else
+        j->rc = lpcn_batch_dev_decode_host(s->dev, j->packets + (size_t)s->first * j->n_packets * 8,
+                                           j->pcm + (size_t)s->first * j->n_packets * 4 * LPCN_FRAME_SIZE, j->n_packets);
+    if (j->rc) snprintf(j->err, sizeof(j->err), "%s", lpcn_last_error());      /* (the engine's message is thread-local) */
+    return NULL;
+}
+
+static int run_shards(LPCNetBatch *b, const shard_job *proto)
+{
+    shard_job job[LPCN_MAX_SHARDS];
+    pthread_t th[LPCN_MAX_SHARDS];
+    int started[LPCN_MAX_SHARDS] = {0};
+    for (int k = 0; k < b->n_shards; k++) { job[k] = *proto; job[k].b = b; job[k].shard = k; job[k].rc = 0; job[k].err[0] = 0; }
+    for (int k = 1; k < b->n_shards; k++) started[k] = pthread_create(&th[k], NULL, shard_worker, &job[k]) == 0;
+    shard_worker(&job[0]);
+    for (int k = 1; k < b->n_shards; k++) { if (started[k]) pthread_join(th[k], NULL); else shard_worker(&job[k]); }
+    for (int k = 0; k < b->n_shards; k++) if (job[k].rc) { set_err(job[k].err); return job[k].rc; }
+    return 0;
+}
 
 int lpcnet_batch_reset(LPCNetBatch *b, int first, int count)
 {
     NEED_MODEL(b);
-    FWD(lpcn_batch_dev_reset(b->dev, first, count));
-}
-
-int lpcnet_batch_synthesize(LPCNetBatch *b, const float *features, int feat_stride, short *pcm, int n_frames)
-{
-    NEED_MODEL(b);
-    FWD(lpcn_batch_dev_run_host(b->dev, features, feat_stride, pcm, n_frames, 0));
+    if (first < 0 || count < 0 || first + count > b->n) { set_err("reset range"); return LPCN_E_ARG; }
+    for (int k = 0; k < b->n_shards; k++) {
+        const batch_shard *s = &b->sh[k];
+        const int lo = first > s->first ? first : s->first;
+        const int hi = first + count < s->first + s->count ? first + count : s->first + s->count;
+        if (hi <= lo) continue;
+        int rc = lpcn_batch_dev_reset(s->dev, lo - s->first, hi - lo);
+        if (rc) { take_engine_err(); return rc; }
+    }
+    return 0;
 }
 
 int lpcnet_batch_synthesize_preload(LPCNetBatch *b, const float *features, int feat_stride, short *pcm, int n_frames, int preload)
 {
     NEED_MODEL(b);
-    FWD(lpcn_batch_dev_run_host(b->dev, features, feat_stride, pcm, n_frames, preload));
+    shard_job j;
+    memset(&j, 0, sizeof(j));
+    j.kind = 0; j.features = features; j.feat_stride = feat_stride; j.pcm = pcm; j.n_frames = n_frames; j.preload = preload;
+    return run_shards(b, &j);
+}
+
+int lpcnet_batch_synthesize(LPCNetBatch *b, const float *features, int feat_stride, short *pcm, int n_frames)
+{
+    return lpcnet_batch_synthesize_preload(b, features, feat_stride, pcm, n_frames, 0);
+}
+
+int lpcnet_batch_synthesize_device_shard(LPCNetBatch *b, int shard, const float *d_features, int feat_stride, short *d_pcm,
+                                         int n_frames, void *hip_stream)
+{
+    NEED_MODEL(b);
+    if (shard < 0 || shard >= b->n_shards) { set_err("shard index"); return LPCN_E_ARG; }
+    FWD(lpcn_batch_dev_run(b->sh[shard].dev, d_features, feat_stride, d_pcm, n_frames, 0, hip_stream));
 }
 
 int lpcnet_batch_synthesize_device(LPCNetBatch *b, const float *d_features, int feat_stride, short *d_pcm, int n_frames, void *hip_stream)
 {
     NEED_MODEL(b);
-    FWD(lpcn_batch_dev_run(b->dev, d_features, feat_stride, d_pcm, n_frames, 0, hip_stream));
+    NEED_ONE_SHARD(b, "lpcnet_batch_synthesize_device");
+    return lpcnet_batch_synthesize_device_shard(b, 0, d_features, feat_stride, d_pcm, n_frames, hip_stream);
 }
 
-int lpcnet_batch_sync(LPCNetBatch *b) { NEED_MODEL(b); FWD(lpcn_batch_dev_sync(b->dev)); }
+int lpcnet_batch_sync(LPCNetBatch *b)
+{
+    NEED_MODEL(b);
+    for (int k = 0; k < b->n_shards; k++) { int rc = lpcn_batch_dev_sync(b->sh[k].dev); if (rc) { take_engine_err(); return rc; } }
+    return 0;
+}
 
-/* the device copy of the VQ codebooks follows lpcnet_hip_set_codebooks() */
+/* the device copies of the VQ codebooks follow lpcnet_hip_set_codebooks() */
 static int batch_codebooks(LPCNetBatch *b)
 {
     pthread_mutex_lock(&g_lock);
     int rc = 0;
+    default_codebooks_locked();
     if (!g_cb[0]) { set_err("lpcnet_batch_decode: no VQ codebooks installed (lpcnet_hip_set_codebooks)"); rc = LPCN_E_MODEL; }
-    else if (b->cb_version != g_cb_version) {
-        rc = lpcn_engine_set_codebooks(b->engine, g_cb[0], g_cb[1], g_cb[2], g_cb[3]);
-        if (rc) take_engine_err(); else b->cb_version = g_cb_version;
-    }
+    for (int k = 0; !rc && k < b->n_shards; k++)
+        if (b->sh[k].cb_version != g_cb_version) {
+            rc = lpcn_engine_set_codebooks(b->sh[k].engine, g_cb[0], g_cb[1], g_cb[2], g_cb[3]);
+            if (rc) take_engine_err(); else b->sh[k].cb_version = g_cb_version;
+        }
     pthread_mutex_unlock(&g_lock);
     return rc;
 }
@@ -468,68 +749,119 @@ int lpcnet_batch_decode(LPCNetBatch *b, const unsigned char *packets, short *pcm
     if (n_packets <= 0) { set_err("lpcnet_batch_decode: bad arguments"); return LPCN_E_ARG; }
     int rc = batch_codebooks(b);
     if (rc) return rc;
-    FWD(lpcn_batch_dev_decode_host(b->dev, packets, pcm, n_packets));
+    shard_job j;
+    memset(&j, 0, sizeof(j));
+    j.kind = 1; j.packets = packets; j.pcm = pcm; j.n_packets = n_packets;
+    return run_shards(b, &j);
 }
 
 /* the same with device pointers, enqueued on the caller's stream (NULL = the batch's own) */
 int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
 {
     NEED_MODEL(b);
+    NEED_ONE_SHARD(b, "lpcnet_batch_decode_device");
     if (n_packets <= 0) { set_err("lpcnet_batch_decode_device: bad arguments"); return LPCN_E_ARG; }
     int rc = batch_codebooks(b);
     if (rc) return rc;
-    FWD(lpcn_batch_dev_decode(b->dev, d_packets, d_pcm, n_packets, hip_stream));
+    FWD(lpcn_batch_dev_decode(b->sh[0].dev, d_packets, d_pcm, n_packets, hip_stream));
 }
+
+#define EACH_SHARD(call) do { for (int k_ = 0; k_ < b->n_shards; k_++) { batch_shard *s = &b->sh[k_]; int rc_ = (call); if (rc_) { take_engine_err(); return rc_; } } return 0; } while (0)
 
 /* LPC_GAMMA of the model (a #define of the reference's generated nnet_data.h, not in the blob); default 1 */
-int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma)
-{
-    NEED_MODEL(b);
-    FWD(lpcn_engine_set_lpc_gamma(b->engine, gamma));
-}
-
+int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma) { NEED_MODEL(b); EACH_SHARD(lpcn_engine_set_lpc_gamma(s->engine, gamma)); }
 /* END2END models (LPC from the network's reflection coefficients); a #define of the reference, not in the blob */
-int lpcnet_batch_set_end2end(LPCNetBatch *b, int on)
+int lpcnet_batch_set_end2end(LPCNetBatch *b, int on) { NEED_MODEL(b); EACH_SHARD(lpcn_engine_set_end2end(s->engine, on)); }
+
+static batch_shard *shard_of(LPCNetBatch *b, int stream)
 {
-    NEED_MODEL(b);
-    FWD(lpcn_engine_set_end2end(b->engine, on));
+    for (int k = 0; k < b->n_shards; k++)
+        if (stream >= b->sh[k].first && stream < b->sh[k].first + b->sh[k].count) return &b->sh[k];
+    return NULL;
 }
+#define SHARD_OF(sv, b, stream) batch_shard *sv = shard_of(b, stream); do { if (!sv) { set_err("stream index"); return LPCN_E_ARG; } } while (0)
 
 int lpcnet_batch_export_state(LPCNetBatch *b, int stream, LPCNetState *st)
 {
     NEED_MODEL(b);
+    SHARD_OF(s, b, stream);
     if (st->magic != LPCN_MAGIC) { st->magic = LPCN_MAGIC; st->model_id = -1; }
-    FWD(lpcn_batch_dev_get_state(b->dev, stream, &st->s));
+    FWD(lpcn_batch_dev_get_state(s->dev, stream - s->first, &st->s));
 }
 
 int lpcnet_batch_import_state(LPCNetBatch *b, int stream, const LPCNetState *st)
 {
     NEED_MODEL(b);
-    FWD(lpcn_batch_dev_set_state(b->dev, stream, &st->s));
+    SHARD_OF(s, b, stream);
+    FWD(lpcn_batch_dev_set_state(s->dev, stream - s->first, &st->s));
 }
 
-int lpcnet_batch_set_streams_per_workgroup(LPCNetBatch *b, int s) { NEED_MODEL(b); FWD(lpcn_batch_dev_set_streams_per_wg(b->dev, s)); }
-int lpcnet_batch_get_streams_per_workgroup(const LPCNetBatch *b) { return b && b->dev ? lpcn_batch_dev_streams_per_wg(b->dev) : 0; }
-int lpcnet_batch_enable_timing(LPCNetBatch *b, int on) { NEED_MODEL(b); FWD(lpcn_batch_dev_enable_timing(b->dev, on)); }
-int lpcnet_batch_last_timing(LPCNetBatch *b, float *ms_s, float *ms_f) { NEED_MODEL(b); FWD(lpcn_batch_dev_last_timing(b->dev, ms_s, ms_f)); }
+int lpcnet_batch_set_streams_per_workgroup(LPCNetBatch *b, int spw) { NEED_MODEL(b); EACH_SHARD(lpcn_batch_dev_set_streams_per_wg(s->dev, spw)); }
+int lpcnet_batch_get_streams_per_workgroup(const LPCNetBatch *b) { return b && b->n_shards && b->sh[0].dev ? lpcn_batch_dev_streams_per_wg(b->sh[0].dev) : 0; }
+int lpcnet_batch_enable_timing(LPCNetBatch *b, int on) { NEED_MODEL(b); EACH_SHARD(lpcn_batch_dev_enable_timing(s->dev, on)); }
+/* kernel milliseconds of the most recent run: the slowest shard */
+int lpcnet_batch_last_timing(LPCNetBatch *b, float *ms_s, float *ms_f)
+{
+    NEED_MODEL(b);
+    float bs = 0.f, bf = 0.f;
+    for (int k = 0; k < b->n_shards; k++) {
+        float a = 0.f, c = 0.f;
+        lpcn_batch_dev_last_timing(b->sh[k].dev, &a, &c);
+        if (a > bs) bs = a;
+        if (c > bf) bf = c;
+    }
+    if (ms_s) *ms_s = bs;
+    if (ms_f) *ms_f = bf;
+    return 0;
+}
 
 int lpcnet_batch_run_tail(LPCNetBatch *b, const float *cond_a, const float *cond_b, const float *lpc, short *pcm, int n_frames, int preload)
 {
     NEED_MODEL(b);
-    FWD(lpcn_batch_dev_run_tail_host(b->dev, cond_a, cond_b, lpc, pcm, n_frames, preload));
+    for (int k = 0; k < b->n_shards; k++) {
+        const batch_shard *s = &b->sh[k];
+        const size_t o = (size_t)s->first * n_frames;
+        int rc = lpcn_batch_dev_run_tail_host(s->dev, cond_a + o * LPCN_ROWS_A, cond_b + o * LPCN_ROWS_B, lpc + o * LPCN_LPC_ORDER,
+                                              pcm + o * LPCN_FRAME_SIZE, n_frames, preload);
+        if (rc) { take_engine_err(); return rc; }
+    }
+    return 0;
 }
 
 int lpcnet_batch_run_frames(LPCNetBatch *b, const float *features, int feat_stride, float *cond_a, float *cond_b, float *lpc, int n_frames)
 {
     NEED_MODEL(b);
-    FWD(lpcn_batch_dev_run_frames_host(b->dev, features, feat_stride, cond_a, cond_b, lpc, n_frames));
+    for (int k = 0; k < b->n_shards; k++) {
+        const batch_shard *s = &b->sh[k];
+        const size_t o = (size_t)s->first * n_frames;
+        int rc = lpcn_batch_dev_run_frames_host(s->dev, features + o * feat_stride, feat_stride, cond_a ? cond_a + o * LPCN_ROWS_A : NULL,
+                                                cond_b ? cond_b + o * LPCN_ROWS_B : NULL, lpc ? lpc + o * LPCN_LPC_ORDER : NULL, n_frames);
+        if (rc) { take_engine_err(); return rc; }
+    }
+    return 0;
 }
 
 int lpcnet_batch_state_size(void) { return (int)sizeof(lpcn_stream_state); }
-int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out) { NEED_MODEL(b); FWD(lpcn_batch_dev_get_state(b->dev, stream, (lpcn_stream_state *)out)); }
-int lpcnet_batch_set_raw_state(LPCNetBatch *b, int stream, const void *in) { NEED_MODEL(b); FWD(lpcn_batch_dev_set_state(b->dev, stream, (const lpcn_stream_state *)in)); }
-int lpcnet_batch_debug_trace(LPCNetBatch *b, int n_samples, float *host_out) { NEED_MODEL(b); FWD(lpcn_batch_dev_debug_trace(b->dev, n_samples, host_out)); }
-int lpcnet_batch_profile(LPCNetBatch *b, unsigned long long *out) { NEED_MODEL(b); FWD(lpcn_batch_dev_profile(b->dev, out)); }
+int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out)
+{
+    NEED_MODEL(b);
+    SHARD_OF(s, b, stream);
+    FWD(lpcn_batch_dev_get_state(s->dev, stream - s->first, (lpcn_stream_state *)out));
+}
+int lpcnet_batch_set_raw_state(LPCNetBatch *b, int stream, const void *in)
+{
+    NEED_MODEL(b);
+    SHARD_OF(s, b, stream);
+    FWD(lpcn_batch_dev_set_state(s->dev, stream - s->first, (const lpcn_stream_state *)in));
+}
+int lpcnet_batch_debug_trace(LPCNetBatch *b, int n_samples, float *host_out) { NEED_MODEL(b); FWD(lpcn_batch_dev_debug_trace(b->sh[0].dev, n_samples, host_out)); }
+int lpcnet_batch_profile(LPCNetBatch *b, unsigned long long *out) { NEED_MODEL(b); FWD(lpcn_batch_dev_profile(b->sh[0].dev, out)); }
+
+int lpcnet_hip_exp10_device(const float *x, double *out, int n)
+{
+    if (!x || !out || n <= 0) { set_err("lpcnet_hip_exp10_device: bad arguments"); return LPCN_E_ARG; }
+    FWD(lpcn_debug_exp10(single_stream_device(), x, out, (size_t)n));
+}
 
 /* Host-only model check (no GPU needed): parses the blob with the loader's rules, builds the device
  * packings and verifies them.  info[0..5] = {is_int8, blocks GRU-A, blocks GRU-B, items per lane,

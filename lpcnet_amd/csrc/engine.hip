@@ -25,6 +25,15 @@ extern "C" const char *lpcn_last_error(void) { return g_err; }
         }                                                                                     \
     } while (0)
 
+// Every entry point selects the engine's device and restores the caller's current device on return.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 struct lpcn_engine {
     int device = 0;
     int nw = 0, nw_variant = 0, nb_b = 0;
@@ -54,9 +63,36 @@ struct lpcn_batch_dev {
     float *d_dbg = nullptr;
     unsigned long long *d_prof = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // Ordering across caller streams: the batch's scratch buffers and state are shared by every call, so each enqueue
+    // records ev_last on its stream; a call on a DIFFERENT stream first waits for it, and every host-side access
+    // (sync, state get/set, reset, destroy, buffer growth) waits for it as well.
+    hipEvent_t ev_last = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    void *h_pin = nullptr;             // pinned host staging of the single-stream fast path (state | features | pcm)
     bool timing = false;
     float ms_sample = 0.f, ms_frame = 0.f;
 };
+
+static int order_begin(lpcn_batch_dev *b, hipStream_t st)
+{
+    if (b->pending && st != b->last_stream) HIP_TRY(hipStreamWaitEvent(st, b->ev_last, 0));
+    return 0;
+}
+static int order_end(lpcn_batch_dev *b, hipStream_t st)
+{
+    HIP_TRY(hipEventRecord(b->ev_last, st));
+    b->last_stream = st;
+    b->pending = true;
+    return 0;
+}
+// host-side wait for everything enqueued for this batch, whichever stream it went to
+static int wait_all(lpcn_batch_dev *b)
+{
+    if (b->pending) { HIP_TRY(hipEventSynchronize(b->ev_last)); b->pending = false; }
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    return 0;
+}
 
 template <typename T>
 static int upload(lpcn_engine *e, const T **dst, const void *src, size_t count)
@@ -88,7 +124,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
                  m->is_int8 ? 64 : 40);
         return LPCN_E_MODEL;
     }
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
     lpcn_engine *e = new lpcn_engine();
     e->device = device;
     e->nw = m->nw; e->nw_variant = nwv; e->nb_b = m->nb_b_padded; e->lpc_gamma = m->lpc_gamma;
@@ -188,7 +224,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
 extern "C" void lpcn_engine_destroy(lpcn_engine *e)
 {
     if (!e) return;
-    (void)hipSetDevice(e->device);
+    DeviceGuard guard(e->device);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -198,14 +234,22 @@ extern "C" int lpcn_engine_device(const lpcn_engine *e) { return e->device; }
 // VQ codebooks of the codec path (the reference's generated ceps_codebooks.c): cb1..3 [1024][17], cb_diff4 [4096][18]
 extern "C" int lpcn_engine_set_codebooks(lpcn_engine *e, const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4)
 {
-    HIP_TRY(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
     int rc = 0;
+    float pitch[64];
+    for (int k = 0; k < 64; ++k) pitch[k] = (float)(pow(2.f, k / 21.) * 32);      // src/lpcnet_dec.c:107 (PITCH_MIN_PERIOD 32)
+    if (e->has_codebooks) {            // a newer codebook version replaces the contents of the buffers already on the device
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemcpy((void *)e->dec.cb1, cb1, sizeof(float) * 1024 * 17, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((void *)e->dec.cb2, cb2, sizeof(float) * 1024 * 17, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((void *)e->dec.cb3, cb3, sizeof(float) * 1024 * 17, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((void *)e->dec.cb_diff4, cb_diff4, sizeof(float) * 4096 * 18, hipMemcpyHostToDevice));
+        return 0;
+    }
     if ((rc = upload<float>(e, &e->dec.cb1, cb1, 1024 * 17))) return rc;
     if ((rc = upload<float>(e, &e->dec.cb2, cb2, 1024 * 17))) return rc;
     if ((rc = upload<float>(e, &e->dec.cb3, cb3, 1024 * 17))) return rc;
     if ((rc = upload<float>(e, &e->dec.cb_diff4, cb_diff4, 4096 * 18))) return rc;
-    float pitch[64];
-    for (int k = 0; k < 64; ++k) pitch[k] = (float)(pow(2.f, k / 21.) * 32);      // src/lpcnet_dec.c:107 (PITCH_MIN_PERIOD 32)
     if ((rc = upload<float>(e, &e->dec.pitch, pitch, 64))) return rc;
     e->has_codebooks = true;
     return 0;
@@ -251,7 +295,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
 {
     *out = nullptr;
     if (!e || n <= 0 || max_chunk <= 0) { snprintf(g_err, sizeof(g_err), "bad batch arguments"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
     lpcn_batch_dev *b = new lpcn_batch_dev();
     b->e = e; b->n = n; b->max_chunk = max_chunk;
     b->S = auto_streams_per_wg(e, n);
@@ -267,6 +311,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
     AL(b->d_vq_mem, sizeof(float) * (size_t)n * LPCN_NB_BANDS);
 #undef AL
     for (auto &ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) return fail(LPCN_E_HIP);
+    if (hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming) != hipSuccess) return fail(LPCN_E_HIP);
     *out = b;
     int rc = lpcn_batch_dev_reset(b, 0, n);
     if (rc) return fail(rc);
@@ -276,8 +321,10 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
 extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
 {
     if (!b) return;
-    (void)hipSetDevice(b->e->device);
-    (void)hipStreamSynchronize(b->e->stream);
+    DeviceGuard guard(b->e->device);
+    (void)wait_all(b);
+    if (b->h_pin) (void)hipHostFree(b->h_pin);
+    if (b->ev_last) (void)hipEventDestroy(b->ev_last);
     void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof,
                     b->d_vq_mem, b->d_packets};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -305,10 +352,10 @@ static void host_reset_state(lpcn_stream_state *st)
 extern "C" int lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count)
 {
     if (first < 0 || count < 0 || first + count > b->n) { snprintf(g_err, sizeof(g_err), "reset range"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     std::vector<lpcn_stream_state> h(count);
     for (auto &s : h) host_reset_state(&s);
-    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    { int rcw = wait_all(b); if (rcw) return rcw; }
     HIP_TRY(hipMemcpy(b->d_state + first, h.data(), sizeof(lpcn_stream_state) * count, hipMemcpyHostToDevice));
     if (count) HIP_TRY(hipMemset(b->d_vq_mem + (size_t)first * LPCN_NB_BANDS, 0, sizeof(float) * (size_t)count * LPCN_NB_BANDS));
     return 0;
@@ -317,16 +364,16 @@ extern "C" int lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count)
 extern "C" int lpcn_batch_dev_get_state(lpcn_batch_dev *b, int s, lpcn_stream_state *host)
 {
     if (s < 0 || s >= b->n) { snprintf(g_err, sizeof(g_err), "stream index"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(b->e->device));
-    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    DeviceGuard guard(b->e->device);
+    { int rcw = wait_all(b); if (rcw) return rcw; }
     HIP_TRY(hipMemcpy(host, b->d_state + s, sizeof(*host), hipMemcpyDeviceToHost));
     return 0;
 }
 extern "C" int lpcn_batch_dev_set_state(lpcn_batch_dev *b, int s, const lpcn_stream_state *host)
 {
     if (s < 0 || s >= b->n) { snprintf(g_err, sizeof(g_err), "stream index"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(b->e->device));
-    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    DeviceGuard guard(b->e->device);
+    { int rcw = wait_all(b); if (rcw) return rcw; }
     HIP_TRY(hipMemcpy(b->d_state + s, host, sizeof(*host), hipMemcpyHostToDevice));
     return 0;
 }
@@ -353,9 +400,8 @@ extern "C" int lpcn_batch_dev_last_timing(lpcn_batch_dev *b, float *ms_sample, f
 }
 extern "C" int lpcn_batch_dev_sync(lpcn_batch_dev *b)
 {
-    HIP_TRY(hipSetDevice(b->e->device));
-    HIP_TRY(hipStreamSynchronize(b->e->stream));
-    return 0;
+    DeviceGuard guard(b->e->device);
+    return wait_all(b);
 }
 
 // ------------------------------------------------------------------------------- launches -----
@@ -425,9 +471,10 @@ extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, in
     if (n_frames <= 0 || feat_stride < LPCN_NB_FEAT || preload < 0 || preload > LPCN_FRAME_SIZE) {
         snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG;
     }
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->e->stream;
     float tf = 0.f, ts = 0.f;
+    { int rco = order_begin(b, st); if (rco) return rco; }
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
         if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
@@ -446,11 +493,12 @@ extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, in
         }
     }
     if (b->timing) { b->ms_frame = tf; b->ms_sample = ts; }
-    return 0;
+    return order_end(b, st);
 }
 
 static int ensure_staging(lpcn_batch_dev *b, size_t feat_floats, size_t pcm_samples)
 {
+    if (feat_floats > b->feat_cap || pcm_samples > b->pcm_cap) { int rcw = wait_all(b); if (rcw) return rcw; }   // the old buffers may still be in use
     if (feat_floats > b->feat_cap) {
         if (b->d_feat) (void)hipFree(b->d_feat);
         b->d_feat = nullptr; b->feat_cap = 0;
@@ -470,11 +518,12 @@ extern "C" int lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features,
                                        short *pcm, int n_frames, int preload)
 {
     if (n_frames <= 0) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     const size_t nfeat = (size_t)b->n * n_frames * feat_stride, npcm = (size_t)b->n * n_frames * LPCN_FRAME_SIZE;
     int rc = ensure_staging(b, nfeat, npcm);
     if (rc) return rc;
     hipStream_t st = b->e->stream;
+    if ((rc = order_begin(b, st))) return rc;      // the staging buffers may still be read by work on a caller stream
     HIP_TRY(hipMemcpyAsync(b->d_feat, features, nfeat * sizeof(float), hipMemcpyHostToDevice, st));
     if (preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pcm, npcm * sizeof(short), hipMemcpyHostToDevice, st));
     rc = lpcn_batch_dev_run(b, b->d_feat, feat_stride, b->d_pcm, n_frames, preload, st);
@@ -484,22 +533,50 @@ extern "C" int lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features,
     return 0;
 }
 
+// Single-stream fast path of the legacy per-frame API (a batch of one stream): one frame-network step + frame_len samples
+// with ONE host synchronisation.  The caller's POD state is uploaded only when it differs from the device copy
+// (st_in == NULL: the device copy is current); features, state and PCM travel through one pinned buffer.
+extern "C" int lpcn_batch_dev_run_single(lpcn_batch_dev *b, const lpcn_stream_state *st_in, const float *feat, short *pcm,
+                                         lpcn_stream_state *st_out)
+{
+    if (b->n != 1) { snprintf(g_err, sizeof(g_err), "run_single needs a batch of one stream"); return LPCN_E_ARG; }
+    DeviceGuard guard(b->e->device);
+    const size_t off_feat = sizeof(lpcn_stream_state), off_pcm = off_feat + LPCN_NB_FEAT * sizeof(float);
+    int rc = ensure_staging(b, LPCN_NB_FEAT, LPCN_FRAME_SIZE);
+    if (rc) return rc;
+    if (!b->h_pin) HIP_TRY(hipHostMalloc(&b->h_pin, off_pcm + LPCN_FRAME_SIZE * sizeof(short), hipHostMallocDefault));
+    hipStream_t st = b->e->stream;
+    if ((rc = order_begin(b, st))) return rc;
+    unsigned char *pin = (unsigned char *)b->h_pin;
+    if (st_in) {
+        memcpy(pin, st_in, sizeof(*st_in));
+        HIP_TRY(hipMemcpyAsync(b->d_state, pin, sizeof(*st_in), hipMemcpyHostToDevice, st));
+    }
+    memcpy(pin + off_feat, feat, LPCN_NB_FEAT * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(b->d_feat, pin + off_feat, LPCN_NB_FEAT * sizeof(float), hipMemcpyHostToDevice, st));
+    rc = lpcn_batch_dev_run(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, 0, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(pin, b->d_state, sizeof(lpcn_stream_state), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(pin + off_pcm, b->d_pcm, LPCN_FRAME_SIZE * sizeof(short), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->pending = false;
+    memcpy(st_out, pin, sizeof(*st_out));
+    memcpy(pcm, pin + off_pcm, (size_t)b->frame_len * sizeof(short));
+    return 0;
+}
+
 // Codec path: 8-byte packets [stream][packet][8] -> 4 frames each.  Device pointers, work only enqueued.
 extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
 {
     if (n_packets <= 0) { snprintf(g_err, sizeof(g_err), "bad decode arguments"); return LPCN_E_ARG; }
     if (!b->e->has_codebooks) { snprintf(g_err, sizeof(g_err), "no VQ codebooks installed (lpcnet_hip_set_codebooks)"); return LPCN_E_MODEL; }
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->e->stream;
     const int T = 4 * n_packets;
-    if (hip_stream == nullptr) {
+    {   // (growing the staging buffer waits for the batch's outstanding work first; it happens once per size)
         int rc = ensure_staging(b, (size_t)b->n * T * LPCN_NB_FEAT, 0);
         if (rc) return rc;
-    } else if ((size_t)b->n * T * LPCN_NB_FEAT > b->feat_cap) {
-        // growing the staging buffer would synchronise the device: do it once, outside the caller's stream
-        HIP_TRY(hipStreamSynchronize(st));
-        int rc = ensure_staging(b, (size_t)b->n * T * LPCN_NB_FEAT, 0);
-        if (rc) return rc;
+        if ((rc = order_begin(b, st))) return rc;
     }
     hipLaunchKernelGGL(lpcn::decode_kernel, dim3((b->n + 1) / 2), dim3(64), 0, st, b->e->dec, d_packets, b->n, n_packets, b->d_vq_mem,
                        b->d_feat, LPCN_NB_FEAT);
@@ -510,9 +587,10 @@ extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_p
 extern "C" int lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char *packets, short *pcm, int n_packets)
 {
     if (n_packets <= 0) { snprintf(g_err, sizeof(g_err), "bad decode arguments"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     const size_t nbytes = (size_t)b->n * n_packets * 8, npcm = (size_t)b->n * n_packets * 4 * LPCN_FRAME_SIZE;
     if (nbytes > b->packets_cap) {
+        { int rcw = wait_all(b); if (rcw) return rcw; }
         if (b->d_packets) (void)hipFree(b->d_packets);
         b->d_packets = nullptr; b->packets_cap = 0;
         HIP_TRY(hipMalloc((void **)&b->d_packets, nbytes));
@@ -521,6 +599,7 @@ extern "C" int lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char
     int rc = ensure_staging(b, 0, npcm);
     if (rc) return rc;
     hipStream_t st = b->e->stream;
+    if ((rc = order_begin(b, st))) return rc;
     HIP_TRY(hipMemcpyAsync(b->d_packets, packets, nbytes, hipMemcpyHostToDevice, st));
     rc = lpcn_batch_dev_decode(b, b->d_packets, b->d_pcm, n_packets, nullptr);
     if (rc) return rc;
@@ -533,11 +612,12 @@ extern "C" int lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond
                                             const float *lpc, short *pcm, int n_frames, int preload)
 {
     if (n_frames <= 0 || preload < 0 || preload > LPCN_FRAME_SIZE) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     const size_t npcm = (size_t)b->n * n_frames * LPCN_FRAME_SIZE;
     int rc = ensure_staging(b, 0, npcm);
     if (rc) return rc;
     hipStream_t st = b->e->stream;
+    if ((rc = order_begin(b, st))) return rc;
     if (preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pcm, npcm * sizeof(short), hipMemcpyHostToDevice, st));
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
@@ -567,11 +647,12 @@ extern "C" int lpcn_batch_dev_run_frames_host(lpcn_batch_dev *b, const float *fe
                                               float *cond_a, float *cond_b, float *lpc, int n_frames)
 {
     if (n_frames <= 0 || feat_stride < LPCN_NB_FEAT) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     const size_t nfeat = (size_t)b->n * n_frames * feat_stride;
     int rc = ensure_staging(b, nfeat, 0);
     if (rc) return rc;
     hipStream_t st = b->e->stream;
+    if ((rc = order_begin(b, st))) return rc;
     HIP_TRY(hipMemcpyAsync(b->d_feat, features, nfeat * sizeof(float), hipMemcpyHostToDevice, st));
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
@@ -591,8 +672,9 @@ extern "C" int lpcn_batch_dev_run_frames_host(lpcn_batch_dev *b, const float *fe
 // debug trace (tests only): allocate / fetch the per-sample trace of workgroup 0, stream 0
 extern "C" int lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, float *host_out)
 {
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     if (host_out == nullptr) {
+        { int rcw = wait_all(b); if (rcw) return rcw; }
         if (b->d_dbg) { (void)hipFree(b->d_dbg); b->d_dbg = nullptr; }
         if (n_samples > 0) {
             HIP_TRY(hipMalloc((void **)&b->d_dbg, sizeof(float) * (size_t)n_samples * LPCN_DBG_STRIDE));
@@ -601,7 +683,7 @@ extern "C" int lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, floa
         return 0;
     }
     if (!b->d_dbg) { snprintf(g_err, sizeof(g_err), "trace not enabled"); return LPCN_E_ARG; }
-    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    { int rcw = wait_all(b); if (rcw) return rcw; }
     HIP_TRY(hipMemcpy(host_out, b->d_dbg, sizeof(float) * (size_t)n_samples * LPCN_DBG_STRIDE, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -609,10 +691,31 @@ extern "C" int lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, floa
 // per-phase shader-clock totals of workgroup 0 / wave 0 (out == NULL: enable + zero; else fetch 8 values)
 extern "C" int lpcn_batch_dev_profile(lpcn_batch_dev *b, unsigned long long *out)
 {
-    HIP_TRY(hipSetDevice(b->e->device));
+    DeviceGuard guard(b->e->device);
     if (!b->d_prof) HIP_TRY(hipMalloc((void **)&b->d_prof, 96 * sizeof(unsigned long long)));
-    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    { int rcw = wait_all(b); if (rcw) return rcw; }
     if (!out) { HIP_TRY(hipMemset(b->d_prof, 0, 96 * sizeof(unsigned long long))); return 0; }
     HIP_TRY(hipMemcpy(out, b->d_prof, 96 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
+}
+
+// test seam: the device's 10^x (lpcnet_exp10.h) for host arrays
+extern "C" int lpcn_debug_exp10(int device, const float *x, double *out, size_t n)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { snprintf(g_err, sizeof(g_err), "no such HIP device"); return LPCN_E_NODEVICE; }
+    DeviceGuard guard(device);
+    float *dx = nullptr;
+    double *dy = nullptr;
+    HIP_TRY(hipMalloc((void **)&dx, n * sizeof(float)));
+    if (hipMalloc((void **)&dy, n * sizeof(double)) != hipSuccess) { (void)hipFree(dx); snprintf(g_err, sizeof(g_err), "hipMalloc failed"); return LPCN_E_HIP; }
+    int rc = 0;
+    if (hipMemcpy(dx, x, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = LPCN_E_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(lpcn::exp10_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const float *)dx, dy, n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, dy, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = LPCN_E_HIP;
+    }
+    (void)hipFree(dx); (void)hipFree(dy);
+    if (rc) snprintf(g_err, sizeof(g_err), "exp10 test kernel failed");
+    return rc;
 }

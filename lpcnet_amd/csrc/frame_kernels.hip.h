@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include "lpcnet_engine.h"
 #include "lpcnet_math.h"
+#include "lpcnet_exp10.h"
 
 struct LpcnFrameModel {
     const float *conv1_w, *conv1_b, *conv2_w, *conv2_b;   // [3][in][128]
@@ -238,7 +239,9 @@ __global__ __launch_bounds__(64 * LPC_WAVES) void lpc_kernel(LpcnFrameModel M, i
             sum = sum + cj * M.tab_idct[lane * LPCN_NB_BANDS + j];
         }
         const float e = (float)((double)sum * sqrt(2. / LPCN_NB_BANDS));
-        ex[wv][lane] = (float)(pow((double)10.f, (double)e) * (double)band_comp[lane]);
+        // pow(10.f, e) in double, then the product with the band compensation rounded to float (src/freq.c:317-318);
+        // lpcn_exp10 is this engine's own correctly rounded 10^e (lpcnet_exp10.h), not the device math library's pow
+        ex[wv][lane] = (float)(lpcn_exp10(e) * (double)band_comp[lane]);
     }
     __syncthreads();
     // band interpolation (src/freq.c:202-215); bin 160 forced to 0 (:286)
@@ -356,6 +359,13 @@ __global__ __launch_bounds__(64 * LPC_WAVES) void lpc_kernel(LpcnFrameModel M, i
             gi *= g;
         }
     }
+}
+
+// test seam: lpcn_exp10 on the device for an array of arguments (tests/test_exp10.py sweeps it against glibc)
+__global__ __launch_bounds__(256) void exp10_kernel(const float *x, double *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = lpcn_exp10(x[i]);
 }
 
 // END2END models (src/lpcnet.c:56-80,107-108): the first 16 outputs of the conditioning network are reflection

@@ -4,7 +4,6 @@
  * Layers:
  *   api.c (C)          public include/lpcnet.h + include/lpcnet_batch.h entry points
  *   model_pack.c (C)   DNNw blob -> validated host model + device-friendly packings
- *   lpc_host.c (C)     lpc_from_cepstrum on the host (used by the single-stream shell only)
  *   engine.hip (HIP)   device memory, uploads, kernel launches  <-- declared here
  */
 #ifndef LPCNET_ENGINE_H
@@ -139,6 +138,10 @@ int  lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, int feat_str
 int  lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features, int feat_stride,
                              short *pcm, int n_frames, int preload);
 int  lpcn_batch_dev_sync(lpcn_batch_dev *b);
+/* Legacy per-frame API on a batch of ONE stream: one frame-network step on feat[0..19] + frame_len samples with a single
+ * host synchronisation.  st_in == NULL: the device copy of the state is current (no upload); st_out receives the new state. */
+int  lpcn_batch_dev_run_single(lpcn_batch_dev *b, const lpcn_stream_state *st_in, const float *feat, short *pcm,
+                               lpcn_stream_state *st_out);
 
 /* Codec path (src/lpcnet_dec.c:81-155 on the device): packets [n][n_packets][8] -> pcm [n][n_packets*640].
  * The VQ memory of every stream lives on the device and is cleared by lpcn_batch_dev_reset. */
@@ -167,6 +170,9 @@ int  lpcn_batch_dev_set_frame_len(lpcn_batch_dev *b, int n);
 int  lpcn_batch_dev_debug_trace(lpcn_batch_dev *b, int n_samples, float *host_out);
 /* per-phase shader-clock totals of workgroup 0 (out == NULL: enable and zero; else fetch 8 values) */
 int  lpcn_batch_dev_profile(lpcn_batch_dev *b, unsigned long long *out);
+
+/* test seam: this engine's own 10^x (lpcnet_exp10.h) evaluated on the device for host arrays */
+int  lpcn_debug_exp10(int device, const float *x, double *out, size_t n);
 
 #ifdef __cplusplus
 }

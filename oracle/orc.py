@@ -159,3 +159,31 @@ class OracleState:
         rng = np.zeros(4, np.uint32)
         self.L.orc_get_signal_state(self.p, ls, C.byref(le), C.byref(dm), C.byref(fc), rng)
         return ls, le.value, dm.value, fc.value, rng
+
+
+# ---- many independent streams on the host cores (tests and bench.py's checker leg) ---------------------------
+def _synth_worker(args):
+    blob, feats, lpc_gamma, end2end = args
+    om = OracleModel(blob, lpc_gamma=lpc_gamma, end2end=end2end)
+    return np.stack([om.new_state().synthesize(f) for f in feats])
+
+
+def synthesize_many(blob: bytes, feats: np.ndarray, workers: int | None = None, lpc_gamma: float = 1.0, end2end: bool = False) -> np.ndarray:
+    """feats (n, T, >=20) -> pcm (n, T*160): n fresh oracle states, spread over a pool of `workers` processes
+    (spawned, so a parent that already initialised HIP is not forked)."""
+    import multiprocessing as mp
+    import os
+    n = feats.shape[0]
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+    workers = max(1, min(workers, n, 32))
+    if workers == 1:
+        return _synth_worker((blob, feats, lpc_gamma, end2end))
+    build()
+    chunks = np.array_split(np.arange(n), workers * 2)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        parts = pool.map(_synth_worker, [(blob, np.ascontiguousarray(feats[c]), lpc_gamma, end2end) for c in chunks if len(c)])
+    return np.concatenate(parts, axis=0)

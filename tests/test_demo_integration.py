@@ -1,0 +1,88 @@
+"""The reference's OWN demo program (src/lpcnet_demo.c, unmodified) on the HIP engine: BASELINE.json configs 0 -> 1.
+
+CPU part (`-m "not gpu"`): where the reference tree is mounted, `make -C integration` compiles src/lpcnet_demo.c in
+place against the reference's headers and links it with liblpcnet_hip.so + integration/stubs_unused_modes.c.
+GPU part: the resulting binary (it travels to the GPU box like the other build outputs under oracle/_ref/) runs
+`-synthesis` on the 10-second / 1000-frame feature file and must write, byte for byte, what the reference's own
+generic-C binaries wrote (tests/golden/golden_demo_v1.npz, made by tests/tools/make_golden_demo.py from
+oracle/_ref/lpcnet_demo_gf / _gi; compared directly as well where those binaries are present), and `-decode`,
+which the reference's demo can only run on a compiled-in model (src/lpcnet_demo.c:176-188), on the process-default
+model and codebooks."""
+import hashlib
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from lpcnet_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "oracle", "_ref", "lpcnet_demo_hip")
+REF_SRC = "/root/reference/src/lpcnet_demo.c"
+GOLDEN = os.path.join(ROOT, "tests", "golden", "golden_demo_v1.npz")
+
+
+def test_reference_demo_links_against_the_engine(hip_lib):
+    if not os.path.exists(REF_SRC):
+        pytest.skip("reference tree not mounted (the binary is prebuilt where it is)")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "integration")])
+    assert os.path.exists(DEMO)
+    needed = subprocess.run(["ldd", DEMO], capture_output=True, text=True).stdout
+    assert "liblpcnet_hip.so" in needed and "not found" not in needed.split("liblpcnet_hip.so")[1].split("\n")[0]
+    syms = subprocess.run(["nm", "-D", "--undefined-only", DEMO], capture_output=True, text=True).stdout
+    for s in ("lpcnet_create", "lpcnet_load_model", "lpcnet_synthesize", "lpcnet_destroy", "lpcnet_decoder_create", "lpcnet_decode"):
+        assert s in syms                                   # resolved by liblpcnet_hip.so, not by the stubs
+    # the modes outside the engine's scope stop with a message instead of doing nothing
+    r = subprocess.run([DEMO, "-features", "/dev/null", "/dev/null"], capture_output=True, text=True)
+    assert r.returncode == 2 and "not part of the LPCNet HIP engine" in r.stderr
+
+
+def _run_demo(tmp_path, flavour, args, extra_files=()):
+    d = str(tmp_path)
+    with open(os.path.join(d, "weights_blob.bin"), "wb") as f:
+        f.write(synth.blob_bytes(synth.make_model(flavour=flavour)))
+    for name, data in extra_files:
+        with open(os.path.join(d, name), "wb") as f:
+            f.write(data)
+    r = subprocess.run([DEMO] + args, cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return np.fromfile(os.path.join(d, args[-1]), np.int16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fl,flavour", [("gf", "float"), ("gi", "int8")])
+def test_demo_synthesis_10s_file_equals_reference_binary(tmp_path, fl, flavour, hip_lib):
+    """`lpcnet_demo_hip -synthesis` on the 1000-frame file == lpcnet_demo_gf / lpcnet_demo_gi (reference, generic C)."""
+    if not os.path.exists(DEMO):
+        pytest.skip("oracle/_ref/lpcnet_demo_hip not built (needs the reference tree: make -C integration)")
+    g = np.load(GOLDEN)
+    T = int(g["n_frames"])
+    feats = synth.make_features(int(g["seed"]), T)
+    pcm = _run_demo(tmp_path, flavour, ["-synthesis", "feat.f32", "out.pcm"], [("feat.f32", feats.astype(np.float32).tobytes())])
+    assert pcm.size == T * 160
+    crc = np.array([zlib.crc32(f.tobytes()) for f in pcm.reshape(-1, 160)], np.uint32)
+    bad = np.nonzero(crc != g[f"{fl}_crc"])[0]
+    assert bad.size == 0, f"first diverging frame {bad[0]} of {T}"
+    assert np.array_equal(np.frombuffer(hashlib.sha256(pcm.tobytes()).digest(), np.uint8), g[f"{fl}_sha256"])
+    assert np.array_equal(pcm[:480], g[f"{fl}_head"]) and np.array_equal(pcm[-160:], g[f"{fl}_tail"])
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", f"lpcnet_demo_{fl}")
+    if os.path.exists(ref_exe):                            # the reference binary itself, side by side (`cmp`)
+        d = str(tmp_path)
+        subprocess.check_call([ref_exe, "-synthesis", "feat.f32", "ref.pcm"], cwd=d)
+        assert open(os.path.join(d, "ref.pcm"), "rb").read() == open(os.path.join(d, "out.pcm"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_demo_decode_on_default_model_and_codebooks(tmp_path, golden, hip_lib):
+    """`lpcnet_demo_hip -decode`: the demo never hands the decoder a model (src/lpcnet_demo.c:176-188); the engine binds
+    ./weights_blob.bin and ./ceps_codebooks.bin as process defaults.  Expected PCM = the real reference's lpcnet_decode
+    on the same packets (golden `packet_pcm_gf`, generated through oracle/_ref)."""
+    if not os.path.exists(DEMO):
+        pytest.skip("oracle/_ref/lpcnet_demo_hip not built")
+    cbs = synth.make_codebooks(5)
+    cb_bytes = b"".join(np.ascontiguousarray(c, np.float32).tobytes() for c in cbs)
+    packets = np.ascontiguousarray(golden["packets"], np.uint8)
+    pcm = _run_demo(tmp_path, "float", ["-decode", "pk.bin", "out.pcm"], [("pk.bin", packets.tobytes()), ("ceps_codebooks.bin", cb_bytes)])
+    assert np.array_equal(pcm, golden["packet_pcm_gf"].reshape(-1))
