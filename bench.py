@@ -10,16 +10,24 @@ step     = one pass of the hot path (frame network + LPC + 160-sample loop per f
            weak scaling: every GPU gets its own 1024 streams = config 3 at N = 8).
 value    = whole-job 16 kHz samples per second (sum over GPUs / max-over-ranks time);
            concurrent real-time streams = value / 16000.
+           Every stream of every rank has its own seeded feature file (1000 + rank*streams + s); after the timed loop
+           `--check-streams` streams of the timed output are replayed on the plain-C oracle (checker leg) and
+           compared bit for bit: `parity_checked` in the JSON line.
+           `--gpus N` without a launcher re-executes itself under `python -m torch.distributed.run` with N ranks.
 roofline = the sample kernel (dominant, >98 % of the step).  SURVEY.md §8(d): not MFMA; the primary bound
            is on-chip operand bandwidth, so `achieved` = algorithmic operand bytes per stream-sample
            (286 704 B fp32 / 96 432 B int8: every weight and table entry once per sample) x samples per
            launch / launch time, against the 150 TB/s LDS peak; the fp32-VALU flop fraction (129 698 flop
-           per sample vs 157.3 TFLOP/s) and the HBM-side fraction (13 857 B per sample vs 8 TB/s) ride
-           along; `traffic` = HBM bytes per launch from the rocprofv3 PMC counters.  Launch time is
+           per sample vs 157.3 TFLOP/s) and the L2-side gather rate (13 857 B per sample, L2 -> CU, NOT HBM)
+           ride along; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this very command
+           (profiles/, FETCH_SIZE x2 + WRITE_SIZE; it cannot be collected from inside the process) and
+           `hbm` = that traffic over the live launch time against the 8 TB/s peak.  Launch time is
            measured live with HIP events on the stream the kernel runs on.
-cpu_baseline = the reference's own AVX2 float build (oracle/_ref, `kind: reference`) or, if that
-           prebuilt library is absent, the plain-C oracle (`kind: port`), timed here on the host
-           cores over a bounded sample.  The oracle is only the baseline/checker, never the product.
+cpu_baseline = the reference's own AVX2 builds (oracle/_ref, `kind: reference`): A-f = float (-DDISABLE_DOT_PROD, the
+           arithmetic the fp32 line is compared with) and A-i = int8, the reference's default x86 build; `value`
+           is A-f for the fp32 line and A-i for the --int8 line, both are listed under `flavours`.  If the
+           prebuilt libraries are absent: the plain-C oracle (`kind: port`).  Timed here on the host cores over a
+           bounded sample.  The oracle is only the baseline/checker, never the product.
 """
 import argparse
 import json
@@ -36,7 +44,7 @@ sys.path.insert(0, ROOT)
 STREAMS_PER_GPU = 1024
 FRAMES_PER_STEP = 25                    # 0.25 s of audio per stream and step
 FLOP_PER_SAMPLE = 129698                # 64 849 MAC
-HBM_BYTES_PER_SAMPLE = 13857            # embedding gather 13 824 + PCM 2 + frame I/O 31
+L2_BYTES_PER_SAMPLE = 13857             # embedding gather 13 824 (L2 -> CU) + PCM 2 + frame I/O 31
 LDS_OPERAND_BYTES_PER_SAMPLE = 286704   # every fp32 operand once per stream-sample
 LDS_OPERAND_BYTES_PER_SAMPLE_I8 = 96432 # int8 GRU-A 59 544 + int8 GRU-B 21 912 + fp32 tree 1 152 + embedding rows 13 824
 PEAK_FP32_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector peak
@@ -47,13 +55,13 @@ MEASURED_FP32_MUL_ADD_TFLOPS = 58.9      # tools/ubench/peaks.hip on this box (p
 
 
 def _cpu_worker(args):
-    kind, frames, seed = args
+    kind, frames, seed, flavour = args
     from lpcnet_amd import synth
-    blob = synth.blob_bytes(synth.make_model())
+    blob = synth.blob_bytes(synth.make_model(flavour="int8" if flavour == "ai" else "float"))
     f = synth.make_features(seed, frames)
     if kind == "reference":
         from oracle import ref
-        lib = ref.RefLib("af")
+        lib = ref.RefLib(flavour)
         st = lib.new_state(blob)
         t0 = time.perf_counter()
         st.synthesize(f)
@@ -87,26 +95,49 @@ def usable_cores():
     return n
 
 
-def cpu_baseline():
+def cpu_baseline(int8_line=False):
     """Reference CPU path on this box's host cores: nproc independent single-threaded processes
-    (the library has no threading), ~10-20 s of CPU work in total."""
+    (the library has no threading), ~10-20 s of CPU work in total; A-f (AVX2 float) and A-i (AVX2 int8, the
+    reference's default x86 build, src/vec_avx.h:39-41)."""
     from oracle import ref
-    kind = "reference" if ref.available("af") else "port"
+    have = ref.available("af") and ref.available("ai")
+    kind = "reference" if have else "port"
     cores = usable_cores()
     procs = max(1, min(cores, 32))
-    frames = 1000 if kind == "reference" else 250        # ~1.3 s (AVX2 float) / ~1.5 s (plain C) per process
-    t0 = time.perf_counter()
-    with mp.get_context("spawn").Pool(procs) as pool:
-        times = pool.map(_cpu_worker, [(kind, frames, 1000 + i) for i in range(procs)])
-    wall = time.perf_counter() - t0
-    samples = procs * (frames - 2) * 160
-    agg = sum((frames - 2) * 160 / tt for tt in times)     # concurrent single-threaded processes, one per usable core
-    one = (frames - 2) * 160 / float(np.median(times))
-    return {"value": agg, "unit": "samples/s", "cores": procs, "kind": kind,
-            "per_core": one,
-            "sample": f"{procs} independent processes x {frames} frames ({frames / 100:.1f} s of audio each), "
-                      f"{'reference AVX2+FMA float build (oracle/_ref af)' if kind == 'reference' else 'plain-C oracle'}; "
-                      f"{cores} usable host cores of {os.cpu_count()}; pool wall {wall:.1f} s"}
+    names = {"af": "reference AVX2+FMA float build (oracle/_ref af, -DDISABLE_DOT_PROD)",
+             "ai": "reference AVX2 int8 build (oracle/_ref ai, the reference's default on x86)", "port": "plain-C oracle"}
+    flav = {}
+    for fl in (("af", "ai") if have else ("port",)):
+        frames = 1000 if have else 250                       # ~1.3 s (A-f) / ~0.7 s (A-i) / ~1.5 s (plain C) per process
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(procs) as pool:
+            times = pool.map(_cpu_worker, [(kind, frames, 1000 + i, fl) for i in range(procs)])
+        wall = time.perf_counter() - t0
+        flav[fl] = {"value": sum((frames - 2) * 160 / tt for tt in times),       # concurrent single-threaded processes, one per usable core
+                    "per_core": (frames - 2) * 160 / float(np.median(times)), "frames_per_process": frames, "pool_wall_s": round(wall, 1),
+                    "build": names[fl]}
+    main = ("ai" if int8_line else "af") if have else "port"
+    frames = flav[main]["frames_per_process"]
+    return {"value": flav[main]["value"], "unit": "samples/s", "cores": procs, "kind": kind, "per_core": flav[main]["per_core"],
+            "flavour": main, "flavours": flav,
+            "sample": f"{procs} independent processes x {frames} frames ({frames / 100:.1f} s of audio each), {names[main]}; "
+                      f"{cores} usable host cores of {os.cpu_count()}"}
+
+
+def _self_launch(a):
+    """`python bench.py --gpus N` without a launcher: become N ranks (one per GPU) under torch.distributed.run."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {have} HIP device(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -118,6 +149,10 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per step")
     ap.add_argument("--spw", type=int, default=0, help="streams per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-streams", type=int, default=8, help="streams of the timed output replayed on the CPU oracle (0 = none)")
+    ap.add_argument("--fast", action="store_true",
+                    help="FAST arithmetic (fused multiply-add / int32 accumulation like the reference's AVX2 builds): a separate, "
+                         "non-bit-exact flavour; the headline is the default PARITY arithmetic")
     ap.add_argument("--int8", action="store_true",
                     help="BASELINE.json config 4: int8 (DOT_PROD) GRU-A/GRU-B weights, bit-exact vs the reference's generic int8 build "
                          "(default: float32 weights, the configuration the metric is quoted on)")
@@ -127,14 +162,17 @@ def main():
     import torch.distributed as dist
     from lpcnet_amd import api, synth
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE {world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus})")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)      # RCCL: control plane only
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the LPCNet HIP engine has no CPU fallback")
     torch.cuda.set_device(local)
@@ -145,9 +183,12 @@ def main():
     batch = api.LPCNetBatch(n, blob, device=local)
     if a.spw:
         batch.streams_per_workgroup = a.spw
-    # synthetic features: 16 distinct seeded streams per rank, tiled over the batch, resident in HBM
-    base = np.stack([synth.make_features(1000 + 16 * rank + i, F) for i in range(16)])
-    d_feat = torch.from_numpy(np.ascontiguousarray(base[np.arange(n) % 16])).to(dev)
+    if a.fast:
+        batch.set_fast(True)
+        a.check_streams = 0                                  # FAST is validated teacher-forced (tests/test_gpu_fast.py), not bit for bit
+    # synthetic features: every stream of every rank has its own seeded feature file, resident in HBM
+    feats = np.stack([synth.make_features(1000 + rank * n + s, F) for s in range(n)])
+    d_feat = torch.from_numpy(feats).to(dev)
     d_pcm = torch.zeros((n, F * 160), dtype=torch.int16, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -170,6 +211,7 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    timed_pcm = d_pcm.clone()                                # output of the last timed step (checked below)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -187,6 +229,19 @@ def main():
     ms_frame = float(np.median([k[1] for k in ks]))
     nonzero = int(torch.count_nonzero(d_pcm).item())
     assert nonzero > 0.5 * d_pcm.numel(), "benchmark output is degenerate"
+    # checker leg (rank 0): replay a few streams of the timed region on the plain-C oracle -- the same features fed
+    # warmup + steps times in a row from reset -- and compare the last step's PCM bit for bit
+    parity_checked = 0
+    if rank == 0 and a.check_streams > 0:
+        from oracle import orc
+        passes = max(a.warmup, 1) + a.steps
+        k = min(a.check_streams, n)
+        pick = sorted({(i * n) // k + (i % 4 if n >= 4 * k else 0) for i in range(k)})
+        want = orc.synthesize_many(blob, np.tile(feats[pick], (1, passes, 1)))[:, -F * 160:]
+        got = timed_pcm[pick].cpu().numpy()
+        if not np.array_equal(got, want):
+            raise SystemExit(f"bench.py: timed output differs from the CPU oracle on streams {[p for p, g, w in zip(pick, got, want) if not np.array_equal(g, w)]}")
+        parity_checked = len(pick)
 
     samples_per_step = n * F * 160
     value = world * samples_per_step * a.steps / elapsed
@@ -196,13 +251,16 @@ def main():
         kernel_rate = samples_per_step / (ms_sample * 1e-3)
         op_bytes = LDS_OPERAND_BYTES_PER_SAMPLE_I8 if a.int8 else LDS_OPERAND_BYTES_PER_SAMPLE
         op_gbs = kernel_rate * op_bytes / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_int8.json" if a.int8 else "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):                           # PMC passes of this command, newest round first
+            tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_int8.json" if a.int8 else f"{rnd}_hbm_traffic.json")
+            if os.path.exists(tpath) and (n, F) == (STREAMS_PER_GPU, FRAMES_PER_STEP):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                    traffic_src = os.path.relpath(tpath, ROOT)
+                    break
+                except Exception:
+                    traffic = None
         out = {
             "metric": "16 kHz samples/sec & concurrent real-time streams, 1/2/4/8 MI355X",
             "value": value, "unit": "samples/s",
@@ -211,14 +269,17 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 weights/activations x f32 accumulate (GRU-A/GRU-B), f32 elsewhere" if a.int8 else "f32", "data": "synthetic",
-            "config": {"workload": f"{n} concurrent streams per GPU x {F} frames ({F * 160} samples) per step, "
+            "parity_checked": parity_checked,
+            "config": {"workload": f"{n} concurrent streams (each with its own feature file) per GPU x {F} frames ({F * 160} samples) per step, "
                                    + ("int8 GRU weights (v_dot4_i32_i8)" if a.int8 else "fp32 weights")
-                                   + ", register-resident block-sparse GRU-A, bit-exact (PARITY) arithmetic",
+                                   + ", register-resident block-sparse GRU-A, "
+                                   + ("FAST arithmetic (FMA / int32 accumulation, not bit-exact)" if a.fast else "bit-exact (PARITY) arithmetic"),
+                       "arithmetic": "fast" if a.fast else "parity",
                        "streams_per_gpu": n, "frames_per_step": F, "streams_per_workgroup": batch.streams_per_workgroup,
                        "sharding": f"{world} x {n} independent streams, no data-path collective"},
             "roofline": {"bound": "lds_operand_bandwidth", "kernel": "lpcn::sample_kernel",
                          "achieved": op_gbs, "peak": PEAK_LDS_TBS * 1e3, "unit": "GB/s",
-                         "frac": op_gbs / (PEAK_LDS_TBS * 1e3), "traffic": traffic,
+                         "frac": op_gbs / (PEAK_LDS_TBS * 1e3), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": ms_sample, "frame_kernels_ms": ms_frame,
                          "operand_bytes_per_sample": op_bytes,
                          "note": "algorithmic operand bytes (each weight/table entry once per stream-sample); the engine keeps "
@@ -227,12 +288,15 @@ def main():
                                        "frac": achieved_tflops / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE,
                                        "measured_mul_add_no_fma_TFLOPs": MEASURED_FP32_MUL_ADD_TFLOPS,
                                        "frac_of_measured_no_fma": achieved_tflops / MEASURED_FP32_MUL_ADD_TFLOPS},
-                         "hbm": {"achieved_GBs": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9, "peak_GBs": PEAK_HBM_GBS,
-                                 "frac": kernel_rate * HBM_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS}},
+                         "l2_gather": {"achieved_GBs": kernel_rate * L2_BYTES_PER_SAMPLE / 1e9, "bytes_per_sample": L2_BYTES_PER_SAMPLE,
+                                       "note": "embedding rows + frame products, L2 -> CU; the tables stay L2-resident, this is not HBM traffic"},
+                         "hbm": None if traffic is None else {"achieved_GBs": traffic / (ms_sample * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                                                              "frac": traffic / (ms_sample * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                              "note": "measured PMC traffic per launch / live launch time: HBM is not a bound of this kernel"}},
         }
         if not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(a.int8)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)

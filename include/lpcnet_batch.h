@@ -67,6 +67,12 @@ LPCNET_EXPORT int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma);
 /* END2END models: the reference's compile-time END2END (src/lpcnet.c:56-80,107-108) -- the LPC filter comes from the
  * first 16 conditioning outputs (reflection coefficients, rc2lpc) instead of the cepstrum; set after lpcnet_batch_load_model */
 LPCNET_EXPORT int lpcnet_batch_set_end2end(LPCNetBatch *b, int on);
+/* Arithmetic flavour of the sample loop.  0 = PARITY (default): every product and sum rounded like the reference's
+ * generic-C build, results bit-identical to it.  1 = FAST: the arithmetic of the reference's own SIMD builds -- fused
+ * multiply-add for float blobs (src/vec_avx.h:790-858), int32 block accumulation for int8 blobs (src/vec_avx.h:690-750) --
+ * not bit-identical to any reference build (those differ among themselves as well); tests/test_gpu_fast.py keeps its
+ * teacher-forced deviation inside the reference's own AVX2-vs-generic envelope. */
+LPCNET_EXPORT int lpcnet_batch_set_fast(LPCNetBatch *b, int on);
 LPCNET_EXPORT int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets,
                                              void *hip_stream);
 

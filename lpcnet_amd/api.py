@@ -96,6 +96,7 @@ def load_library():
     L.lpcnet_batch_decode_device.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lpcnet_batch_set_lpc_gamma.argtypes = [vp, C.c_float]
     L.lpcnet_batch_set_end2end.argtypes = [vp, C.c_int]
+    L.lpcnet_batch_set_fast.argtypes = [vp, C.c_int]
     L.lpcnet_batch_export_state.argtypes = [vp, C.c_int, vp]
     L.lpcnet_batch_import_state.argtypes = [vp, C.c_int, vp]
     L.lpcnet_batch_set_streams_per_workgroup.argtypes = [vp, C.c_int]
@@ -312,6 +313,10 @@ class LPCNetBatch:
 
     def set_end2end(self, on: bool = True):
         self._chk(self.L.lpcnet_batch_set_end2end(self.p, int(on)), "set_end2end")
+
+    def set_fast(self, on: bool = True):
+        """FAST arithmetic (FMA / int32 accumulation); default is PARITY (bit-exact)"""
+        self._chk(self.L.lpcnet_batch_set_fast(self.p, int(on)), "set_fast")
 
     def decode_device(self, d_packets_ptr: int, d_pcm_ptr: int, n_packets: int, hip_stream: int = 0):
         self._chk(self.L.lpcnet_batch_decode_device(self.p, d_packets_ptr, d_pcm_ptr, n_packets, hip_stream or None), "decode_device")

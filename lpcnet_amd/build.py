@@ -48,9 +48,16 @@ def build(force=False, verbose=True, prof=False):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    o = os.path.join(objdir, "engine.o")
-    run([HIPCC] + HIP_FLAGS + (["-DLPCN_ENABLE_PROF=1"] + (["-DLPCN_PROF_MASK=" + os.environ["LPCN_PROF_MASK"]] if "LPCN_PROF_MASK" in os.environ else []) if prof else []) + ["-c", os.path.join(CSRC, "engine.hip"), "-o", o])
-    objs.append(o)
+    # engine.hip + the sample kernel's variants, one translation unit per streams-per-workgroup value: built in parallel
+    pf = ["-DLPCN_ENABLE_PROF=1"] + (["-DLPCN_PROF_MASK=" + os.environ["LPCN_PROF_MASK"]] if "LPCN_PROF_MASK" in os.environ else []) if prof else []
+    extra = os.environ.get("LPCN_EXTRA_FLAGS", "").split()
+    jobs = [([HIPCC] + HIP_FLAGS + pf + extra + ["-c", os.path.join(CSRC, "engine.hip"), "-o", os.path.join(objdir, "engine.o")])]
+    for sv in (1, 2, 4):
+        jobs.append([HIPCC] + HIP_FLAGS + pf + extra + [f"-DLPCN_S={sv}", "-c", os.path.join(CSRC, "sample_variants.hip"), "-o", os.path.join(objdir, f"sample_s{sv}.o")])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs += [j[-1] for j in jobs]
     for c in ("api.c", "model_pack.c"):
         o = os.path.join(objdir, c[:-2] + ".o")
         run(["gcc"] + C_FLAGS + ["-c", os.path.join(CSRC, c), "-o", o])

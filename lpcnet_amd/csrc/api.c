@@ -773,6 +773,10 @@ int lpcnet_batch_set_lpc_gamma(LPCNetBatch *b, float gamma) { NEED_MODEL(b); EAC
 /* END2END models (LPC from the network's reflection coefficients); a #define of the reference, not in the blob */
 int lpcnet_batch_set_end2end(LPCNetBatch *b, int on) { NEED_MODEL(b); EACH_SHARD(lpcn_engine_set_end2end(s->engine, on)); }
 
+/* arithmetic flavour: 0 = PARITY (default, bit-identical to the reference's generic-C build), 1 = FAST (what the
+ * reference's own SIMD builds do: fused multiply-add / int32 block accumulation; validated teacher-forced) */
+int lpcnet_batch_set_fast(LPCNetBatch *b, int on) { NEED_MODEL(b); EACH_SHARD(lpcn_engine_set_fast(s->engine, on)); }
+
 static batch_shard *shard_of(LPCNetBatch *b, int stream)
 {
     for (int k = 0; k < b->n_shards; k++)

@@ -38,6 +38,7 @@ struct lpcn_engine {
     int device = 0;
     int nw = 0, nw_variant = 0, nb_b = 0;
     bool is_int8 = false;
+    bool fast = false;                 // FAST arithmetic (lpcn_engine_set_fast): fused / integer accumulation instead of the reference's generic-C order
     float lpc_gamma = 1.f;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
@@ -263,6 +264,13 @@ extern "C" int lpcn_engine_set_end2end(lpcn_engine *e, int on)
     e->fmodel.end2end = on != 0;
     return 0;
 }
+// FAST arithmetic: what the reference's own SIMD builds do (src/vec_avx.h) -- fused multiply-add for float blobs, exact
+// int32 block accumulation for int8 blobs -- instead of the generic-C order.  Not bit-exact; validated teacher-forced.
+extern "C" int lpcn_engine_set_fast(lpcn_engine *e, int on)
+{
+    e->fast = on != 0;
+    return 0;
+}
 extern "C" int lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma)
 {
     if (!(gamma > 0.f && gamma <= 1.f)) { snprintf(g_err, sizeof(g_err), "lpc_gamma must be in (0, 1]"); return LPCN_E_ARG; }
@@ -405,38 +413,11 @@ extern "C" int lpcn_batch_dev_sync(lpcn_batch_dev *b)
 }
 
 // ------------------------------------------------------------------------------- launches -----
-template <int S, int NW, bool I8>
-static int launch_sample_t(lpcn_batch_dev *b, hipStream_t st, bool dbg)
-{
-    const int lds = lpcn::Lds<S>::total(b->e->nb_b, I8);
-    const int grid = (b->n + S - 1) / S;
-    (void)dbg;
-    auto k = lpcn::sample_kernel<S, NW, I8>;
-    HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(LPCN_WG_THREADS), lds, st, (const LpcnSampleArgs *)b->d_args);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int S>
-static int launch_sample_s(lpcn_batch_dev *b, hipStream_t st, bool dbg)
-{
-    if (b->e->is_int8) {
-        switch (b->e->nw_variant) {
-        case 32: return launch_sample_t<S, 32, true>(b, st, dbg);
-        case 48: return launch_sample_t<S, 48, true>(b, st, dbg);
-        default: return launch_sample_t<S, 64, true>(b, st, dbg);
-        }
-    }
-    switch (b->e->nw_variant) {
-    case 24: return launch_sample_t<S, 24, false>(b, st, dbg);
-    case 28: return launch_sample_t<S, 28, false>(b, st, dbg);
-    case 30: return launch_sample_t<S, 30, false>(b, st, dbg);
-    case 32: return launch_sample_t<S, 32, false>(b, st, dbg);
-    case 36: return launch_sample_t<S, 36, false>(b, st, dbg);
-    default: return launch_sample_t<S, 40, false>(b, st, dbg);
-    }
-}
+// The sample kernel's variants (streams per workgroup x items per lane x blob flavour x arithmetic) are compiled in
+// separate translation units, one per streams-per-workgroup value (sample_variants.hip), so they build in parallel.
+extern "C" int lpcn_launch_sample_s1(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
+extern "C" int lpcn_launch_sample_s2(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
+extern "C" int lpcn_launch_sample_s4(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
 
 // one chunk of the per-sample kernel; cond_a/cond_b/lpc for the chunk are already in the batch buffers
 static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t pcm_stride, int n_frames,
@@ -450,12 +431,15 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
     a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
     HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
-    const bool dbg = b->d_dbg != nullptr;
+    const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0, fast = b->e->fast ? 1 : 0;
+    int lds = 0, rc = 0;
     switch (b->S) {
-    case 1: return launch_sample_s<1>(b, st, dbg);
-    case 2: return launch_sample_s<2>(b, st, dbg);
-    default: return launch_sample_s<4>(b, st, dbg);
+    case 1: lds = lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(b->e->nw_variant, i8, fast, grid, lds, st, b->d_args); break;
+    case 2: lds = lpcn::Lds<2>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s2(b->e->nw_variant, i8, fast, grid, lds, st, b->d_args); break;
+    default: lds = lpcn::Lds<4>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s4(b->e->nw_variant, i8, fast, grid, lds, st, b->d_args); break;
     }
+    if (rc) { snprintf(g_err, sizeof(g_err), "sample kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return LPCN_E_HIP; }
+    return 0;
 }
 
 static int launch_frames(lpcn_batch_dev *b, hipStream_t st, const float *d_feat, int feat_stride,

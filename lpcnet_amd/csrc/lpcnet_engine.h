@@ -149,6 +149,7 @@ int  lpcn_engine_set_codebooks(lpcn_engine *e, const float *cb1, const float *cb
 int  lpcn_engine_has_codebooks(const lpcn_engine *e);
 int  lpcn_engine_set_end2end(lpcn_engine *e, int on);              /* END2END of the model's nnet_data.h (default off) */
 int  lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma);     /* LPC_GAMMA of the model's nnet_data.h (default 1) */
+int  lpcn_engine_set_fast(lpcn_engine *e, int on);                /* FAST arithmetic (not bit-exact; default off = PARITY) */
 int  lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream);
 int  lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char *packets, short *pcm, int n_packets);
 

@@ -142,6 +142,19 @@ template <int SEL> __device__ __forceinline__ float quad_bcast(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SEL * 0x55, 0xf, 0xf, true));
 }
 
+// FAST float path: acc += w * (h held by lane quad_base + SEL) as ONE v_fmac_f32_dpp (VOP2 with a DPP source).  hipcc
+// does not fold a DPP move into a fused multiply-add (it emits v_mov_b32_dpp + v_fma_f32), hence inline assembly.
+// DPP hazard: a VGPR written by a VALU instruction must not be read through DPP in the next two issue slots; `h` is
+// always the destination of an LDS read here, and tools/kernel_resources.py --check-dpp verifies it on the assembly.
+template <int SEL> __device__ __forceinline__ float fmac_quad(float acc, const float w, const float h)
+{
+    if constexpr (SEL == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w));
+    if constexpr (SEL == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w));
+    if constexpr (SEL == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w));
+    if constexpr (SEL == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w));
+    return acc;
+}
+
 // int8 (DOT_PROD) arithmetic of the reference's generic-C build, src/vec.h:274-339:
 //   x_q = (signed char)(int)floor(.5 + 127*x)   (float product, double sum)
 //   out = out*(128*127);  out += (w0*x0 + w1*x1 + w2*x2 + w3*x3) per block (exact integer);  out *= 1/128/127
@@ -208,8 +221,37 @@ template <int J> __device__ __forceinline__ float lpc_chain(float r, float prod)
     else return r;
 }
 
-template <int S, int NW, bool I8>
-__global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
+// Waves per SIMD the register allocation must leave room for: 2 = one 8-wave workgroup per CU (256 VGPRs per lane);
+// 4 = two workgroups per CU (128 VGPRs), which only the int8 FAST variants with S <= 2 reach without spilling inside
+// the sample loop (tools/kernel_resources.py): two independent workgroups fill each other's barrier / latency bubbles.
+#ifndef LPCN_MIN_WAVES_PER_EU
+#define LPCN_MIN_WAVES_PER_EU(S, I8, FAST) (((I8) && (FAST) && (S) <= 2) ? 4 : 2)
+#endif
+
+// Accumulator of one GRU row while its items run, kept in a float VGPR:
+//   PARITY, float blob : the float sum itself (src/vec.h:355-401)
+//   PARITY, int8 blob  : the float sum scaled by 128*127, one exactly-integer block product added at a time (src/vec.h:306-339)
+//   FAST,   int8 blob  : the bit pattern of an int32 -- start value rounded once to the 1/(128*127) grid, blocks
+//                        accumulated exactly by v_dot4_i32_i8, converted back at the end: the arithmetic of the
+//                        reference's AVX2 int8 build (src/vec_avx.h:700-705,742-744 and :803-858)
+template <bool I8, bool FAST> __device__ __forceinline__ float acc_start(float v)
+{
+    if constexpr (I8 && FAST) return __builtin_bit_cast(float, (int)__builtin_rintf(v * QS));
+    else if constexpr (I8) return v * QS;
+    else return v;
+}
+template <bool I8, bool FAST> __device__ __forceinline__ float acc_final(float a)
+{
+    if constexpr (I8 && FAST) return (float)__builtin_bit_cast(int, a) * QS1;
+    else if constexpr (I8) return a * QS1;
+    else return a;
+}
+
+// FAST = the arithmetic of the reference's SIMD builds instead of its generic-C order: fused multiply-add for float
+// blobs (src/vec_avx.h:790-858 _mm256_fmadd_ps), int32 block accumulation for int8 blobs (see acc_start).  Results are
+// no longer bit-identical to the generic-C build; tests/test_gpu_fast.py bounds the deviation teacher-forced.
+template <int S, int NW, bool I8, bool FAST>
+__global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST)) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
 {
     using L = Lds<S>;
     using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
@@ -533,7 +575,16 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             auto mac = [&](const int j) {
                 // one item = (this lane's row) x (one 4-wide input block) for all S streams; per output
                 // the products are added in block order, columns 0..3 (src/vec.h:355-401)
-                if constexpr (I8) {
+                if constexpr (I8 && FAST) {
+                    // int32 accumulation across the row's blocks (exact; src/vec_avx.h:823-845)
+                    const HT xv = hq[j % (PF + 1)];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        int xs;
+                        if constexpr (S == 1) xs = xv; else xs = xv[s];
+                        acc[s] = __builtin_bit_cast(float, __builtin_amdgcn_sdot4(w[j], xs, __builtin_bit_cast(int, acc[s]), false));
+                    }
+                } else if constexpr (I8) {
                     // one dot4 = the row's block product for one stream, exact in int32 (src/vec.h:329-334)
                     const HT xv = hq[j % (PF + 1)];
                     if constexpr (S == 4) {
@@ -554,7 +605,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 const float wk[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if constexpr (S == 1) {
+                    if constexpr (FAST) {                    // fused multiply-add (v_fmac_f32 with the DPP operand folded in)
+                        if constexpr (S == 1) acc[0] = __builtin_fmaf(wk[c], hk[c], acc[0]);
+                        if constexpr (S >= 2) { acc[0] = fmac_quad<0>(acc[0], wk[c], hk[c]); acc[1] = fmac_quad<1>(acc[1], wk[c], hk[c]); }
+                        if constexpr (S == 4) { acc[2] = fmac_quad<2>(acc[2], wk[c], hk[c]); acc[3] = fmac_quad<3>(acc[3], wk[c], hk[c]); }
+                    } else if constexpr (S == 1) {
                         acc[0] = acc[0] + wk[c] * hk[c];
                     } else if constexpr (S == 2) {
                         const float t0 = wk[c] * quad_bcast<0>(hk[c]), t1 = wk[c] * quad_bcast<1>(hk[c]);
@@ -600,7 +655,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     const float g = ((pre_c[slot][s] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
                     if (candidate && live_row) sm_inh[n * S + s] = g;
                     float v = candidate ? b : b + g;
-                    if constexpr (I8) v = v * QS;
+                    v = acc_start<I8, FAST>(v);
                     if (to_acc) acc[s] = v; else if (live_row && park) sm_pre[r * S + s] = v;
                 }
             };
@@ -610,7 +665,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 LPCN_REMAT_V(r2);
                 if (r >= 0 && store_done) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc_final<I8, FAST>(acc[s]);
                 }
                 r2 = r2 < 0 ? 0 : r2;
 #pragma unroll
@@ -621,7 +676,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = I8 ? acc[s] * QS1 : acc[s];
+                    for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc_final<I8, FAST>(acc[s]);
                 }
             };
             // Waves whose first slot holds only candidate rows (the big ones) start it from
@@ -654,8 +709,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    acc[s] = bias + diag * sm_hT[n * S + s];
-                    if constexpr (I8) acc[s] = acc[s] * QS;
+                    acc[s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
                 }
             }
             // issue priority for the part of GRU-A that everybody waits for: int8 -- the younger wave of each SIMD pair sees
@@ -813,7 +867,45 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 const int g = r >> 3, ri = r & 7;
                 float zrh = sm_bbias[r] + sm_condb[s * RB + r];               // src/nnet.c:351
                 float rec = sm_bbias[RB + r];
-                if constexpr (I8) {
+                if constexpr (I8 && FAST) {
+                    // int32 accumulation like the reference's AVX2 int8 build (src/vec_avx.h:690-750): start values rounded
+                    // to the 1/(128*127) grid, exact block sums; integer addition is associative, so the four blocks of a
+                    // 16-byte weight read feed four independent chains
+                    typedef int i4 __attribute__((ext_vector_type(4)));
+                    int rsum = (int)__builtin_rintf(rec * QS);
+                    int z0 = (int)__builtin_rintf(zrh * QS), z1 = 0, z2 = 0, z3 = 0;
+                    const i4 wr = ((const i4 *)(smem + L::brec))[r];
+                    const i4 hb = *(const i4 *)(smem + L::hBq + s * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rsum = __builtin_amdgcn_sdot4(wr[k], hb[k], rsum, false);
+                    rec = (float)rsum * QS1;
+                    const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
+                    const int nq = (bend - bbeg) >> 2;
+                    const i4 *wq = (const i4 *)(smem + L::bw) + (bbeg >> 2) * 8 + ri;
+                    const unsigned char *xb = smem + L::xqT + s * 384;
+                    if (b_dense) {
+                        const i4 *xq4 = (const i4 *)xb;      // all 96 input blocks in order: 24 quads, 8 quads of reads in flight
+#pragma unroll 3
+                        for (int q = 0; q < 24; ++q) {
+                            const i4 w4 = wq[q * 8], x4 = xq4[q];
+                            z0 = __builtin_amdgcn_sdot4(w4[0], x4[0], z0, false);
+                            z1 = __builtin_amdgcn_sdot4(w4[1], x4[1], z1, false);
+                            z2 = __builtin_amdgcn_sdot4(w4[2], x4[2], z2, false);
+                            z3 = __builtin_amdgcn_sdot4(w4[3], x4[3], z3, false);
+                        }
+                    } else {
+                        const uint2 *offs = (const uint2 *)(sm_boff + bbeg);
+                        for (int q = 0; q < nq; ++q) {
+                            const i4 w4 = wq[q * 8];
+                            const uint2 o = offs[q];
+                            z0 = __builtin_amdgcn_sdot4(w4[0], *(const int *)(xb + (o.x & 0xFFFFu)), z0, false);
+                            z1 = __builtin_amdgcn_sdot4(w4[1], *(const int *)(xb + (o.x >> 16)), z1, false);
+                            z2 = __builtin_amdgcn_sdot4(w4[2], *(const int *)(xb + (o.y & 0xFFFFu)), z2, false);
+                            z3 = __builtin_amdgcn_sdot4(w4[3], *(const int *)(xb + (o.y >> 16)), z3, false);
+                        }
+                    }
+                    zrh = (float)((z0 + z1) + (z2 + z3)) * QS1;
+                } else if constexpr (I8) {
                     typedef int i4 __attribute__((ext_vector_type(4)));
                     zrh = zrh * QS;
                     rec = rec * QS;
@@ -948,8 +1040,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                     const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        acc[s] = bias + diag * sm_hT[n * S + s];
-                        if constexpr (I8) acc[s] = acc[s] * QS;
+                        acc[s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
                     }
                 }
 #pragma unroll
@@ -973,11 +1064,16 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
             // ------------------------------------------ P4: dual-FC tree, all nodes at once --
             {
                 const int node_level = node > 0 ? 31 - __clz(node) : 0;
+                // (tried: the S x 16 GRU-B state values through one LDS read per lane + v_readlane into SGPR operands instead of
+                // S x 4 broadcast ds_read_b128 per wave: P4 2.2 k -> 2.8 k clk, the 64 v_readlane cost more than the reads)
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     float sum = fcb;
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) sum = sum + fcw[j] * sm_hB[s * NB + j];   // src/nnet.c:194-199
+                    for (int j = 0; j < NB; ++j) {                                          // src/nnet.c:194-199
+                        if constexpr (FAST) sum = __builtin_fmaf(fcw[j], sm_hB[s * NB + j], sum);
+                        else sum = sum + fcw[j] * sm_hB[s * NB + j];
+                    }
                     const float v = fcf * lpcn_tanh(sum, sm_tansig);
                     // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
                     const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
@@ -1077,7 +1173,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS) void sample_kernel(const LpcnSampl
                 if (tid < NB) d[384 + tid] = sm_hB[tid];
             }
             // no workgroup barrier here (see above); keep the compiler from mixing the two samples' code
-            asm volatile("" ::: "memory");
+            // (the comment marks the bottom of the sample loop in the assembly: tools/kernel_resources.py)
+            asm volatile("; LPCN_SAMPLE_LOOP_END" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             LPCN_PROF(4);
         }

@@ -1,0 +1,46 @@
+// Instantiations of the persistent sample kernel for ONE streams-per-workgroup value (compile with -DLPCN_S=1|2|4):
+// items per lane (register-resident GRU-A variants) x blob flavour (fp32 / int8) x arithmetic (PARITY / FAST).
+// Split from engine.hip so that the three values build in parallel.
+#include "sample_kernel.hip.h"
+
+#ifndef LPCN_S
+#error "compile with -DLPCN_S=1, 2 or 4"
+#endif
+#define LPCN_CAT2(a, b) a##b
+#define LPCN_CAT(a, b) LPCN_CAT2(a, b)
+
+template <int NW, bool I8, bool FAST>
+static int launch(int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
+{
+    auto k = lpcn::sample_kernel<LPCN_S, NW, I8, FAST>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(LPCN_WG_THREADS), lds, st, d_args);
+    return (int)hipGetLastError();
+}
+
+template <bool FAST>
+static int pick(int nw, int is_int8, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
+{
+    if (is_int8) {
+        switch (nw) {
+        case 32: return launch<32, true, FAST>(grid, lds, st, d_args);
+        case 48: return launch<48, true, FAST>(grid, lds, st, d_args);
+        default: return launch<64, true, FAST>(grid, lds, st, d_args);
+        }
+    }
+    switch (nw) {
+    case 24: return launch<24, false, FAST>(grid, lds, st, d_args);
+    case 28: return launch<28, false, FAST>(grid, lds, st, d_args);
+    case 30: return launch<30, false, FAST>(grid, lds, st, d_args);
+    case 32: return launch<32, false, FAST>(grid, lds, st, d_args);
+    case 36: return launch<36, false, FAST>(grid, lds, st, d_args);
+    default: return launch<40, false, FAST>(grid, lds, st, d_args);
+    }
+}
+
+// returns a hipError_t value (0 = launched)
+extern "C" int LPCN_CAT(lpcn_launch_sample_s, LPCN_S)(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
+{
+    return fast ? pick<true>(nw, is_int8, grid, lds, st, d_args) : pick<false>(nw, is_int8, grid, lds, st, d_args);
+}

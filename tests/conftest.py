@@ -6,6 +6,15 @@ import sys
 import numpy as np
 import pytest
 
+# PyTorch wheels bundle their own copy of the HIP runtime (torch/lib/libamdhip64.so).  A process must use ONE HIP runtime:
+# if liblpcnet_hip.so (linked against /opt/rocm) initialises the GPU first and torch is imported afterwards, torch loads
+# its second copy and reports "No HIP GPUs are available".  Importing torch first makes both share torch's copy -- the
+# same order bench.py uses.  (C programs such as the reference's lpcnet_demo never load torch and use /opt/rocm's.)
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,39 @@
+"""Register / scratch budget of the benchmarked sample-kernel variants, from the compiler's own assembly (no GPU).
+VERDICT r1: `sample_kernel<4,30,false>` reports 15 spilled VGPRs; the spills are loop-invariant values of the FRAME loop
+(spilled once before it, reloaded per frame) -- not one scratch access may sit inside the per-sample loop, and the int8
+variants must not spill at all.  Also checks the DPP hazard of the hand-written v_fmac_f32_dpp of the FAST flavour."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def rows(tmp_path_factory):
+    import kernel_resources as kr
+    path = str(tmp_path_factory.mktemp("asm") / "sample_s4.s")
+    kr.compile_asm(4, path)                                 # ~1 minute: every S = 4 variant, device code only
+    return {(r["NW"], r["int8"], r["fast"]): r for r in kr.analyse(path)}
+
+
+def test_no_scratch_access_inside_the_sample_loop(rows):
+    assert len(rows) == 18
+    for key in [(24, False, False), (28, False, False), (30, False, False), (32, False, False), (30, False, True),
+                (32, True, False), (48, True, False), (64, True, False), (32, True, True)]:
+        r = rows[key]
+        assert r["sample_loop_asm_lines"] and r["sample_loop_asm_lines"] > 3000, key      # the loop was found
+        assert r["scratch_insts_in_sample_loop"] == 0, (key, r)
+        assert r["vgpr"] <= 256
+    for nw in (32, 48, 64):                                 # int8 weights are one VGPR per item: no spills at all
+        assert rows[(nw, True, False)]["vgpr_spill"] == 0 and rows[(nw, True, False)]["scratch_bytes"] == 0
+    # the benchmarked fp32 variant: its spills (frame-loop invariants) stay bounded
+    assert rows[(30, False, False)]["vgpr_spill"] <= 16
+
+
+def test_fast_fmac_dpp_hazards(rows):
+    for key, r in rows.items():
+        if key[2] and not key[1]:
+            assert r["fmac_dpp"] >= 16 * key[0] and r["dpp_hazard_violations"] == 0, key

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Register / scratch accounting of the sample kernel's variants from the compiler's own output (no GPU needed).
+
+    python tools/kernel_resources.py [--s 4] [--asm-dir DIR] [--json]
+
+Compiles lpcnet_amd/csrc/sample_variants.hip for gfx950 to assembly (device only, same flags as lpcnet_amd/build.py),
+then reports per kernel: VGPR / SGPR counts, spill counts, scratch bytes (the .amdhsa metadata), and how many scratch
+accesses sit INSIDE the per-sample loop.  The loop is delimited in the assembly by the kernel's own marker comments
+(`; LPCN_SAMPLE_LOOP_END` at the bottom of the loop body; the loop header is the target of the backward branch that
+follows it).  tests/test_kernel_resources.py asserts on the result so a spill in the hot loop cannot come back unnoticed.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def compile_asm(s_value, out_path):
+    from lpcnet_amd import build
+    cmd = [build.HIPCC] + build.HIP_FLAGS + [f"-DLPCN_S={s_value}", "--cuda-device-only", "-S",
+                                             os.path.join(build.CSRC, "sample_variants.hip"), "-o", out_path]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+
+
+def demangle(name):
+    m = re.match(r"_ZN4lpcn13sample_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)EEE", name)
+    return None if not m else dict(S=int(m.group(1)), NW=int(m.group(2)), int8=bool(int(m.group(3))), fast=bool(int(m.group(4))))
+
+
+def analyse(asm_path):
+    text = open(asm_path).read()
+    lines = text.split("\n")
+    # ---- function bodies
+    bodies = {}
+    cur = None
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(_ZN4lpcn13sample_kernel\w+):\s*(;.*)?$", ln)
+        if m:
+            cur = m.group(1)
+            bodies[cur] = [i, None]
+        elif cur and ".end_amdhsa_kernel" in ln:
+            bodies[cur][1] = i
+            cur = None
+    # ---- metadata (YAML at the end): one record per kernel
+    meta = {}
+    for rec in re.split(r"\n\s+- \.agpr_count:", text)[1:]:
+        nm = re.search(r"\.name:\s+(\S+)", rec)
+        if not nm:
+            continue
+        get = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", rec).group(1))
+        meta[nm.group(1)] = dict(vgpr=get("vgpr_count"), sgpr=get("sgpr_count"), vgpr_spill=get("vgpr_spill_count"),
+                                 sgpr_spill=get("sgpr_spill_count"), scratch_bytes=get("private_segment_fixed_size"))
+    out = []
+    for name, (a, b) in bodies.items():
+        info = demangle(name)
+        if info is None or b is None:
+            continue
+        body = lines[a:b]
+        labels = {m.group(1): k for k, ln in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", ln)] if m}
+        ends = [k for k, ln in enumerate(body) if "LPCN_SAMPLE_LOOP_END" in ln]
+        in_loop = None
+        loop_lines = None
+        if ends:
+            end = ends[-1]
+            # the loop's backward branch: first branch after the marker whose target label lies before the marker
+            head = None
+            for k in range(end, len(body)):
+                m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", body[k])
+                if m and m.group(1) in labels and labels[m.group(1)] < end:
+                    head = labels[m.group(1)]
+                    break
+            if head is not None:
+                region = body[head:end]
+                in_loop = sum(1 for ln in region if re.search(r"\bscratch_(load|store)", ln))
+                loop_lines = len(region)
+        # DPP read-after-VALU-write hazard of the hand-written v_fmac_f32_dpp (the assembler's hazard recogniser cannot
+        # see inside inline asm): its DPP source must not be written by a VALU instruction in the two preceding slots
+        dpp_viol = 0
+        insts = [ln.strip() for ln in body if ln.startswith("\t") and not ln.strip().startswith((".", ";"))]
+        for k, ins in enumerate(insts):
+            m = re.match(r"v_fmac_f32_dpp (v\d+), (v\d+),", ins)
+            if not m:
+                continue
+            src = m.group(2)
+            for prev in insts[max(0, k - 2):k]:
+                pm = re.match(r"(v_\w+) (v\d+|v\[\d+:\d+\])", prev)
+                if pm and not prev.startswith("v_fmac_f32_dpp") and pm.group(2) == src:
+                    dpp_viol += 1
+        total = sum(1 for ln in body if re.search(r"\bscratch_(load|store)", ln))
+        rec = dict(name=name, **info, **meta.get(name, {}), scratch_insts=total, scratch_insts_in_sample_loop=in_loop, sample_loop_asm_lines=loop_lines,
+                   fmac_dpp=sum(1 for i in insts if i.startswith("v_fmac_f32_dpp")), dpp_hazard_violations=dpp_viol)
+        out.append(rec)
+    return sorted(out, key=lambda r: (r["S"], r["int8"], r["fast"], r["NW"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--s", type=int, default=4)
+    ap.add_argument("--asm-dir", default=None)
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    d = a.asm_dir or tempfile.mkdtemp(prefix="lpcn_asm_")
+    path = os.path.join(d, f"sample_s{a.s}.s")
+    if not os.path.exists(path):
+        compile_asm(a.s, path)
+    rows = analyse(path)
+    if a.json:
+        print(json.dumps(rows, indent=1))
+        return
+    print(f"# {path}")
+    print("S NW int8 fast | vgpr sgpr vgpr_spill sgpr_spill scratch_B | scratch insts: total / in sample loop (loop asm lines)")
+    for r in rows:
+        print(f"{r['S']} {r['NW']:2d} {int(r['int8'])}    {int(r['fast'])}    | {r.get('vgpr', -1):4d} {r.get('sgpr', -1):4d} {r.get('vgpr_spill', -1):6d} {r.get('sgpr_spill', -1):10d} "
+              f"{r.get('scratch_bytes', -1):9d} | {r['scratch_insts']:3d} / {r['scratch_insts_in_sample_loop']} ({r['sample_loop_asm_lines']})"
+              + (f" | v_fmac_f32_dpp {r['fmac_dpp']}, hazard violations {r['dpp_hazard_violations']}" if r['fmac_dpp'] else ""))
+
+
+if __name__ == "__main__":
+    main()
