@@ -8,12 +8,18 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
-timeout 300 python bench.py --int8 --no-cpu-baseline > $OUT/bench_i8.json 2> $OUT/bench_i8.err
+timeout 300 python bench.py --int8 > $OUT/bench_i8.json 2> $OUT/bench_i8.err
 timeout 300 python bench.py --streams 1 --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err      # BASELINE config 1
+timeout 300 python bench.py --fast --no-cpu-baseline > $OUT/bench_f32_fast.json 2> $OUT/bench_f32_fast.err
+timeout 300 python bench.py --int8 --fast --spw 2 --no-cpu-baseline > $OUT/bench_i8_fast.json 2> $OUT/bench_i8_fast.err
+# BASELINE configs 0 -> 1: the reference's own demo on the engine vs its AVX2 builds, one 10-s feature file (wall seconds incl. process start)
+python tools/rtf_demo.py > $OUT/rtf_demo.json 2> $OUT/rtf_demo.err
 for fl in f32 i8; do
   flag=""; [ $fl = i8 ] && flag="--int8"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
 done
+python tools/profile_sq.py --tag r02 > $OUT/sq_f32.log 2>&1
+python tools/profile_sq.py --int8 --tag r02 > $OUT/sq_i8.log 2>&1
 find $OUT -name "*.csv" | head -40

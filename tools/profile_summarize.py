@@ -4,7 +4,7 @@ import csv, glob, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 def one(pattern):
     f = glob.glob(os.path.join(SRC, pattern), recursive=True)       # gpurun merges runs: take the newest
@@ -44,7 +44,13 @@ for fl, suffix in (("f32", ""), ("i8", "_int8")):
                        "launch": "1024 streams x 25 frames x 160 samples = 4 096 000 output samples",
                        "command": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace)"},
                       open(os.path.join(DST, f"{RND}_hbm_traffic{suffix}.json"), "w"), indent=1)
-b = os.path.join(SRC, "bench_single.json")
-if os.path.exists(b) and os.path.getsize(b):
-    shutil.copy(b, os.path.join(DST, f"{RND}_bench_single_stream.json"))
+for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_fast.json", "bench_n1_fast.json"),
+                 ("bench_i8_fast.json", "bench_n1_int8_fast.json"), ("rtf_demo.json", "demo_single_stream_rtf.json")):
+    b = os.path.join(SRC, src)
+    if os.path.exists(b) and os.path.getsize(b):
+        shutil.copy(b, os.path.join(DST, f"{RND}_{dst}"))
+for fl, suffix in (("f32", ""), ("i8", "_int8")):
+    b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(DST, f"{RND}_sq_counters{suffix}.csv"))
 print(sorted(os.listdir(DST)))
