@@ -861,6 +861,21 @@ int lpcnet_batch_set_raw_state(LPCNetBatch *b, int stream, const void *in)
 int lpcnet_batch_debug_trace(LPCNetBatch *b, int n_samples, float *host_out) { NEED_MODEL(b); FWD(lpcn_batch_dev_debug_trace(b->sh[0].dev, n_samples, host_out)); }
 int lpcnet_batch_profile(LPCNetBatch *b, unsigned long long *out) { NEED_MODEL(b); FWD(lpcn_batch_dev_profile(b->sh[0].dev, out)); }
 
+/* tools: how GRU-A's rows were dealt to the 8 waves of the sample kernel: out[0] = items per lane, then per wave
+ * {bound[0..3], allh[0..2]} (item index where each slot starts / slot holds only candidate rows) */
+int lpcnet_hip_model_layout(const unsigned char *data, int len, int *out)
+{
+    lpcn_model_host m;
+    if (lpcn_model_parse(&m, data, len) != 0) { set_err("malformed or incomplete DNNw weight blob"); return -1; }
+    out[0] = m.nw;
+    for (int w = 0; w < LPCN_WAVES; w++) {
+        for (int k = 0; k < 4; k++) out[1 + w * 7 + k] = m.pk_a_bound[w][k];
+        for (int k = 0; k < 3; k++) out[1 + w * 7 + 4 + k] = m.pk_a_allh[w][k];
+    }
+    lpcn_model_release(&m);
+    return 0;
+}
+
 int lpcnet_hip_exp10_device(const float *x, double *out, int n)
 {
     if (!x || !out || n <= 0) { set_err("lpcnet_hip_exp10_device: bad arguments"); return LPCN_E_ARG; }

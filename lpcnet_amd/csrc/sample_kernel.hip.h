@@ -852,6 +852,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST)
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             // prefetch this lane's dual-FC row (node = tid>>1, channel = tid&1); it lands while GRU-B
             // runs.  Re-fetched every sample: 18 VGPRs that must not stay live across the GRU-A loop.
+            // (tried: the GRU-B waves issue these loads only after their mat-vec -- the ~0.1 k clk saved in front of GRU-B
+            // come back as a later tree phase: 102.3 vs 102.2 M samples/s, not kept)
             const int node = tid >> 1, chan = tid & 1;
             const auto *fcw_ptr = as_global(Ap->fc_w) + node * 2 * NB + chan * NB;
             float fcw[NB];
