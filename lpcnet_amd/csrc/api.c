@@ -775,7 +775,16 @@ int lpcnet_batch_set_end2end(LPCNetBatch *b, int on) { NEED_MODEL(b); EACH_SHARD
 
 /* arithmetic flavour: 0 = PARITY (default, bit-identical to the reference's generic-C build), 1 = FAST (what the
  * reference's own SIMD builds do: fused multiply-add / int32 block accumulation; validated teacher-forced) */
-int lpcnet_batch_set_fast(LPCNetBatch *b, int on) { NEED_MODEL(b); EACH_SHARD(lpcn_engine_set_fast(s->engine, on)); }
+int lpcnet_batch_set_fast(LPCNetBatch *b, int on)
+{
+    NEED_MODEL(b);
+    for (int k = 0; k < b->n_shards; k++) {
+        int rc = lpcn_engine_set_fast(b->sh[k].engine, on);
+        if (!rc) rc = lpcn_batch_dev_retune(b->sh[k].dev);
+        if (rc) { take_engine_err(); return rc; }
+    }
+    return 0;
+}
 
 static batch_shard *shard_of(LPCNetBatch *b, int stream)
 {

@@ -51,6 +51,7 @@ struct lpcn_engine {
 struct lpcn_batch_dev {
     lpcn_engine *e = nullptr;
     int n = 0, max_chunk = 0, S = 0, frame_len = LPCN_FRAME_SIZE;
+    bool S_auto = true;                // streams per workgroup follow the cost model (re-evaluated when the arithmetic flavour changes)
     lpcn_stream_state *d_state = nullptr;
     int *d_fc_base = nullptr;
     float *d_cond_a = nullptr, *d_cond_b = nullptr, *d_lpc = nullptr, *d_cond = nullptr;
@@ -288,11 +289,14 @@ static int auto_streams_per_wg(const lpcn_engine *e, int n)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     static const float step_f32[3] = {6.5f, 7.6f, 9.9f}, step_i8[3] = {4.4f, 5.5f, 7.3f};
-    const float *step = e->is_int8 ? step_i8 : step_f32;
+    static const float step_f32_fast[3] = {6.0f, 7.0f, 8.9f}, step_i8_fast[3] = {4.4f, 6.5f, 7.0f};   // (int8 FAST, S <= 2: two workgroups share a CU)
+    const float *step = e->fast ? (e->is_int8 ? step_i8_fast : step_f32_fast) : (e->is_int8 ? step_i8 : step_f32);
     int best = 1;
     float best_t = 0.f;
     for (int k = 0; k < 3; ++k) {
-        const int S = 1 << k, wgs = (n + S - 1) / S, rounds = (wgs + cus - 1) / cus;
+        const int S = 1 << k, wgs = (n + S - 1) / S;
+        const int per_cu = (e->is_int8 && S <= 2 && e->nw_variant <= 32) ? 2 : 1;   // the 128-VGPR variants (sample_kernel.hip.h: LPCN_MIN_WAVES_PER_EU)
+        const int rounds = (wgs + cus * per_cu - 1) / (cus * per_cu);
         const float t = rounds * step[k];
         if (k == 0 || t < best_t) { best = S; best_t = t; }
     }
@@ -386,8 +390,15 @@ extern "C" int lpcn_batch_dev_set_state(lpcn_batch_dev *b, int s, const lpcn_str
     return 0;
 }
 extern "C" int lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b) { return b->S; }
+// the engine's arithmetic flavour changed: re-run the cost model unless the caller pinned the value
+extern "C" int lpcn_batch_dev_retune(lpcn_batch_dev *b)
+{
+    if (b->S_auto) b->S = auto_streams_per_wg(b->e, b->n);
+    return 0;
+}
 extern "C" int lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s)
 {
+    b->S_auto = s == 0;
     if (s == 0) s = auto_streams_per_wg(b->e, b->n);
     if (s != 1 && s != 2 && s != 4) { snprintf(g_err, sizeof(g_err), "streams per workgroup must be 1, 2 or 4"); return LPCN_E_ARG; }
     b->S = s;

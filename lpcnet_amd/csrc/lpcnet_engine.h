@@ -125,6 +125,7 @@ int  lpcn_batch_dev_get_state(lpcn_batch_dev *b, int stream, lpcn_stream_state *
 int  lpcn_batch_dev_set_state(lpcn_batch_dev *b, int stream, const lpcn_stream_state *host);
 int  lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b);
 int  lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s);              /* 1,2,4 (0=auto) */
+int  lpcn_batch_dev_retune(lpcn_batch_dev *b);                                 /* after lpcn_engine_set_fast: auto value again */
 
 /* Run n_frames frames (frame network + LPC + 160-sample loop each) for every stream.
  *   features : [n_streams][n_frames][feat_stride] floats, only [0..19] of each frame are read

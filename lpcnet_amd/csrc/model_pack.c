@@ -20,6 +20,7 @@ static int blob_walk(const unsigned char *p, int len, blob_rec *out, int cap)
         if (len < 64) return -1;
         memcpy(h, p, sizeof(h));
         if (h[3] <= 0 || h[4] < h[3] || h[4] > len - 64) return -1;
+        if (h[4] & 3) return -1;                    /* records are read as 4-byte words: the padded size keeps them aligned */
         if (p[63] != 0) return -1;                  /* name[43] must terminate the string      */
         if (n == cap) return -1;
         out[n].name = (const char *)(p + 20);
@@ -54,8 +55,8 @@ static const int *blob_need_idx(const blob_rec *r, int n, const char *name, int 
     int remain = e->size / 4;
     while (remain > 0) {
         int cnt = *idx++;
-        if (cnt < 0 || remain < cnt + 1) return NULL;
-        for (int i = 0; i < cnt; i++) {
+        if (cnt < 0 || cnt > remain - 1) return NULL;     /* (no cnt + 1: the count comes from an untrusted blob) */
+        for (int i = 0; i < cnt; i++) {             /* (order and repeats are the exporter's business: the reference accepts them, and so does the packing) */
             int pos = *idx++;
             if (pos < 0 || pos + 3 >= nb_in || (pos & 3)) return NULL;
         }

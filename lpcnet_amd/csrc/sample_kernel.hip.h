@@ -222,10 +222,11 @@ template <int J> __device__ __forceinline__ float lpc_chain(float r, float prod)
 }
 
 // Waves per SIMD the register allocation must leave room for: 2 = one 8-wave workgroup per CU (256 VGPRs per lane);
-// 4 = two workgroups per CU (128 VGPRs), which only the int8 FAST variants with S <= 2 reach without spilling inside
-// the sample loop (tools/kernel_resources.py): two independent workgroups fill each other's barrier / latency bubbles.
+// 4 = two workgroups per CU (128 VGPRs), which the int8 variants with S <= 2 and <= 32 items per lane reach without
+// spilling inside the sample loop (tools/kernel_resources.py): two independent workgroups fill each other's barrier /
+// latency bubbles.
 #ifndef LPCN_MIN_WAVES_PER_EU
-#define LPCN_MIN_WAVES_PER_EU(S, I8, FAST) (((I8) && (FAST) && (S) <= 2) ? 4 : 2)
+#define LPCN_MIN_WAVES_PER_EU(S, I8, FAST, NW) (((I8) && (S) <= 2 && (NW) <= 32) ? 4 : 2)
 #endif
 
 // Accumulator of one GRU row while its items run, kept in a float VGPR:
@@ -251,7 +252,7 @@ template <bool I8, bool FAST> __device__ __forceinline__ float acc_final(float a
 // blobs (src/vec_avx.h:790-858 _mm256_fmadd_ps), int32 block accumulation for int8 blobs (see acc_start).  Results are
 // no longer bit-identical to the generic-C build; tests/test_gpu_fast.py bounds the deviation teacher-forced.
 template <int S, int NW, bool I8, bool FAST>
-__global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST)) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
+__global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST, NW)) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
 {
     using L = Lds<S>;
     using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
@@ -930,6 +931,19 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST)
                         // all 96 input blocks in order: 24 quads, software-pipelined in batches of 4 quads
                         // (8 LDS reads in flight while the previous batch feeds the dependent add chain)
                         const i4 *xq4 = (const i4 *)xb;
+                        if constexpr (LPCN_MIN_WAVES_PER_EU(S, I8, FAST, NW) > 2) {
+                            // 128-VGPR variants (two workgroups per CU): the other workgroup hides the LDS latency, a
+                            // two-quad pipeline is enough and keeps the kernel out of scratch memory
+                            i4 w0 = wq[0], x0 = xq4[0];
+#pragma unroll 2
+                            for (int q = 0; q < 24; ++q) {
+                                const i4 w1 = wq[(q + 1) * 8], x1 = xq4[q + 1];     // (past the end on the last trip: padded / unused)
+                                float d[4];
+                                dot4_cvt_x4(d, w0[0], w0[1], w0[2], w0[3], x0[0], x0[1], x0[2], x0[3]);
+                                zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3];
+                                w0 = w1; x0 = x1;
+                            }
+                        } else {
                         i4 wA[4], xA[4], wB[4], xB[4];
 #define LPCN_LDQ(W, X, Q0) _Pragma("unroll") for (int k = 0; k < 4; ++k) { W[k] = wq[((Q0) + k) * 8]; X[k] = xq4[(Q0) + k]; }
 #define LPCN_CPQ(W, X) _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                          \
@@ -950,6 +964,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST)
                         }
 #undef LPCN_LDQ
 #undef LPCN_CPQ
+                        }
                     } else {
                         const uint2 *offs = (const uint2 *)(sm_boff + bbeg);
                         for (int q = 0; q < nq; ++q) {

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -107,3 +108,23 @@ def test_product_does_not_link_or_import_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip")):
                 text = open(os.path.join(root, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text and "lpcnet_oracle.h" not in text, f
+
+
+def test_index_stream_with_hostile_count_is_rejected(blob_f32):
+    """an index stream whose block count is INT_MAX must not overflow the bounds check"""
+    m = synth.make_model()
+    idx = m.get("gru_b_weights_idx").copy()
+    idx[0] = 0x7FFFFFFF
+    m.add("gru_b_weights_idx", idx, synth.WEIGHT_TYPE_INT)
+    assert api.check_model(synth.blob_bytes(m))[0] == -1
+
+
+def test_bench_refuses_a_rank_count_it_cannot_get():
+    """`python bench.py --gpus N` must end up with N ranks or fail loudly -- never print an n_gpus: 1 line for N > 1"""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+    env["WORLD_SIZE"] = "2"; env["RANK"] = "0"; env["LOCAL_RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
