@@ -52,6 +52,7 @@ struct lpcn_batch_dev {
     lpcn_engine *e = nullptr;
     int n = 0, max_chunk = 0, S = 0, frame_len = LPCN_FRAME_SIZE;
     bool S_auto = true;                // streams per workgroup follow the cost model (re-evaluated when the arithmetic flavour changes)
+    bool pack2 = false;                // 128-VGPR variant: two workgroups per CU (int8, <= 32 items per lane, more workgroups than CUs)
     lpcn_stream_state *d_state = nullptr;
     int *d_fc_base = nullptr;
     float *d_cond_a = nullptr, *d_cond_b = nullptr, *d_lpc = nullptr, *d_cond = nullptr;
@@ -283,21 +284,38 @@ extern "C" int lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma)
 // ------------------------------------------------------------------------------------ batches --
 // Streams per workgroup: one workgroup occupies a CU, so a batch runs in ceil(workgroups / CUs) rounds; a round with S
 // interleaved streams costs step[S] (measured us per sample step, tests/tools/gpu_sweep.py).  Pick the cheapest.
+// (measured, us per sample step: tests/tools/gpu_sweep.py, tools/gpu_call_*.sh)
+static int device_cus(const lpcn_engine *e)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
+    return 256;
+}
+static bool pack2_available(const lpcn_engine *e) { return e->is_int8 && e->nw_variant <= 32; }
+static bool use_pack2(const lpcn_engine *e, int n, int S)
+{
+    const char *force = getenv("LPCNET_HIP_PACK2");          // tools / tests: "0" never, "1" whenever the variant exists
+    // (S = 4 needs ~92 KB of LDS per workgroup: two do not fit a CU, and the 128-VGPR code alone is slower -- measured 119 vs 137 M)
+    if (S > 2 || !pack2_available(e)) return false;
+    if (force && *force) return *force == '1';
+    return (n + S - 1) / S > device_cus(e);
+}
 static int auto_streams_per_wg(const lpcn_engine *e, int n)
 {
-    int cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const int cus = device_cus(e);
     static const float step_f32[3] = {6.5f, 7.6f, 9.9f}, step_i8[3] = {4.4f, 5.5f, 7.3f};
-    static const float step_f32_fast[3] = {6.0f, 7.0f, 8.9f}, step_i8_fast[3] = {4.4f, 6.5f, 7.0f};   // (int8 FAST, S <= 2: two workgroups share a CU)
+    static const float step_f32_fast[3] = {6.0f, 7.0f, 8.9f}, step_i8_fast[3] = {4.4f, 5.0f, 7.0f};
+    // PACK2 (two int8 workgroups per CU): time of a round in which every CU carries two workgroups
+    static const float pair_i8[3] = {5.8f, 7.3f, 8.6f}, pair_i8_fast[3] = {5.2f, 6.3f, 7.6f};
     const float *step = e->fast ? (e->is_int8 ? step_i8_fast : step_f32_fast) : (e->is_int8 ? step_i8 : step_f32);
+    const float *pair = e->fast ? pair_i8_fast : pair_i8;
     int best = 1;
     float best_t = 0.f;
     for (int k = 0; k < 3; ++k) {
         const int S = 1 << k, wgs = (n + S - 1) / S;
-        const int per_cu = (e->is_int8 && S <= 2 && e->nw_variant <= 32) ? 2 : 1;   // the 128-VGPR variants (sample_kernel.hip.h: LPCN_MIN_WAVES_PER_EU)
-        const int rounds = (wgs + cus * per_cu - 1) / (cus * per_cu);
-        const float t = rounds * step[k];
+        float t;
+        if (use_pack2(e, n, S)) t = (float)((wgs + 2 * cus - 1) / (2 * cus)) * pair[k];
+        else t = (float)((wgs + cus - 1) / cus) * step[k];
         if (k == 0 || t < best_t) { best = S; best_t = t; }
     }
     return best;
@@ -311,6 +329,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
     lpcn_batch_dev *b = new lpcn_batch_dev();
     b->e = e; b->n = n; b->max_chunk = max_chunk;
     b->S = auto_streams_per_wg(e, n);
+    b->pack2 = use_pack2(e, n, b->S);
     auto fail = [&](int code) { lpcn_batch_dev_destroy(b); return code; };
 #define AL(ptr, bytes) if (hipMalloc((void **)&ptr, (bytes)) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) failed", (size_t)(bytes)); return fail(LPCN_E_HIP); }
     AL(b->d_state, sizeof(lpcn_stream_state) * n);
@@ -394,6 +413,7 @@ extern "C" int lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b) { return b
 extern "C" int lpcn_batch_dev_retune(lpcn_batch_dev *b)
 {
     if (b->S_auto) b->S = auto_streams_per_wg(b->e, b->n);
+    b->pack2 = use_pack2(b->e, b->n, b->S);
     return 0;
 }
 extern "C" int lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s)
@@ -402,6 +422,7 @@ extern "C" int lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s)
     if (s == 0) s = auto_streams_per_wg(b->e, b->n);
     if (s != 1 && s != 2 && s != 4) { snprintf(g_err, sizeof(g_err), "streams per workgroup must be 1, 2 or 4"); return LPCN_E_ARG; }
     b->S = s;
+    b->pack2 = use_pack2(b->e, b->n, b->S);
     return 0;
 }
 extern "C" int lpcn_batch_dev_set_frame_len(lpcn_batch_dev *b, int n)
@@ -426,9 +447,9 @@ extern "C" int lpcn_batch_dev_sync(lpcn_batch_dev *b)
 // ------------------------------------------------------------------------------- launches -----
 // The sample kernel's variants (streams per workgroup x items per lane x blob flavour x arithmetic) are compiled in
 // separate translation units, one per streams-per-workgroup value (sample_variants.hip), so they build in parallel.
-extern "C" int lpcn_launch_sample_s1(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
-extern "C" int lpcn_launch_sample_s2(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
-extern "C" int lpcn_launch_sample_s4(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
+extern "C" int lpcn_launch_sample_s1(int nw, int is_int8, int flags, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
+extern "C" int lpcn_launch_sample_s2(int nw, int is_int8, int flags, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
+extern "C" int lpcn_launch_sample_s4(int nw, int is_int8, int flags, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
 
 // one chunk of the per-sample kernel; cond_a/cond_b/lpc for the chunk are already in the batch buffers
 static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t pcm_stride, int n_frames,
@@ -442,7 +463,8 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
     a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
     HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
-    const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0, fast = b->e->fast ? 1 : 0;
+    const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0;
+    const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);
     int lds = 0, rc = 0;
     switch (b->S) {
     case 1: lds = lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(b->e->nw_variant, i8, fast, grid, lds, st, b->d_args); break;

@@ -221,13 +221,12 @@ template <int J> __device__ __forceinline__ float lpc_chain(float r, float prod)
     else return r;
 }
 
-// Waves per SIMD the register allocation must leave room for: 2 = one 8-wave workgroup per CU (256 VGPRs per lane);
-// 4 = two workgroups per CU (128 VGPRs), which the int8 variants with S <= 2 and <= 32 items per lane reach without
-// spilling inside the sample loop (tools/kernel_resources.py): two independent workgroups fill each other's barrier /
-// latency bubbles.
-#ifndef LPCN_MIN_WAVES_PER_EU
-#define LPCN_MIN_WAVES_PER_EU(S, I8, FAST, NW) (((I8) && (S) <= 2 && (NW) <= 32) ? 4 : 2)
-#endif
+// PACK2 variants: the register allocation leaves room for 4 waves per SIMD (128 VGPRs per lane), i.e. TWO workgroups per
+// CU, which fill each other's barrier / latency bubbles (measured: a second resident workgroup slows the first by only
+// ~15 %).  Only the int8 kernels with <= 32 items per lane and S <= 2 get there without a scratch access inside the
+// sample loop (tools/kernel_resources.py), and only their LDS footprint (~66 KB) lets two workgroups share a CU; S = 4 would
+// need 128 VGPRs AND <= 80 KB (it has ~92 KB): tried, 119 vs 137 M samples/s.  The engine picks a PACK2 variant when a
+// batch has more workgroups than the device has CUs.
 
 // Accumulator of one GRU row while its items run, kept in a float VGPR:
 //   PARITY, float blob : the float sum itself (src/vec.h:355-401)
@@ -251,8 +250,8 @@ template <bool I8, bool FAST> __device__ __forceinline__ float acc_final(float a
 // FAST = the arithmetic of the reference's SIMD builds instead of its generic-C order: fused multiply-add for float
 // blobs (src/vec_avx.h:790-858 _mm256_fmadd_ps), int32 block accumulation for int8 blobs (see acc_start).  Results are
 // no longer bit-identical to the generic-C build; tests/test_gpu_fast.py bounds the deviation teacher-forced.
-template <int S, int NW, bool I8, bool FAST>
-__global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST, NW)) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
+template <int S, int NW, bool I8, bool FAST, bool PACK2 = false>
+__global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
 {
     using L = Lds<S>;
     using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
@@ -931,7 +930,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, LPCN_MIN_WAVES_PER_EU(S, I8, FAST,
                         // all 96 input blocks in order: 24 quads, software-pipelined in batches of 4 quads
                         // (8 LDS reads in flight while the previous batch feeds the dependent add chain)
                         const i4 *xq4 = (const i4 *)xb;
-                        if constexpr (LPCN_MIN_WAVES_PER_EU(S, I8, FAST, NW) > 2) {
+                        if constexpr (PACK2) {
                             // 128-VGPR variants (two workgroups per CU): the other workgroup hides the LDS latency, a
                             // two-quad pipeline is enough and keeps the kernel out of scratch memory
                             i4 w0 = wq[0], x0 = xq4[0];

@@ -9,10 +9,10 @@
 #define LPCN_CAT2(a, b) a##b
 #define LPCN_CAT(a, b) LPCN_CAT2(a, b)
 
-template <int NW, bool I8, bool FAST>
+template <int NW, bool I8, bool FAST, bool PACK2 = false>
 static int launch(int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
 {
-    auto k = lpcn::sample_kernel<LPCN_S, NW, I8, FAST>;
+    auto k = lpcn::sample_kernel<LPCN_S, NW, I8, FAST, PACK2>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(LPCN_WG_THREADS), lds, st, d_args);
@@ -20,11 +20,11 @@ static int launch(int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_arg
 }
 
 template <bool FAST>
-static int pick(int nw, int is_int8, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
+static int pick(int nw, int is_int8, int pack2, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
 {
     if (is_int8) {
         switch (nw) {
-        case 32: return launch<32, true, FAST>(grid, lds, st, d_args);
+        case 32: return (pack2 && LPCN_S <= 2) ? launch<32, true, FAST, (LPCN_S <= 2)>(grid, lds, st, d_args) : launch<32, true, FAST>(grid, lds, st, d_args);
         case 48: return launch<48, true, FAST>(grid, lds, st, d_args);
         default: return launch<64, true, FAST>(grid, lds, st, d_args);
         }
@@ -40,7 +40,9 @@ static int pick(int nw, int is_int8, int grid, int lds, hipStream_t st, const Lp
 }
 
 // returns a hipError_t value (0 = launched)
-extern "C" int LPCN_CAT(lpcn_launch_sample_s, LPCN_S)(int nw, int is_int8, int fast, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
+// flags: bit 0 = FAST arithmetic, bit 1 = PACK2 (two workgroups per CU; int8, 32 items per lane only)
+extern "C" int LPCN_CAT(lpcn_launch_sample_s, LPCN_S)(int nw, int is_int8, int flags, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
 {
-    return fast ? pick<true>(nw, is_int8, grid, lds, st, d_args) : pick<false>(nw, is_int8, grid, lds, st, d_args);
+    const int pack2 = (flags >> 1) & 1;
+    return (flags & 1) ? pick<true>(nw, is_int8, pack2, grid, lds, st, d_args) : pick<false>(nw, is_int8, pack2, grid, lds, st, d_args);
 }

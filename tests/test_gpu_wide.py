@@ -43,6 +43,30 @@ def test_256_distinct_streams_against_oracle(flavour, n, T, S, hip_lib):
     b.close()
 
 
+@pytest.mark.parametrize("n,S", [(600, 2), (300, 1)], ids=["S2", "S1"])
+def test_int8_two_workgroups_per_cu_variants(n, S, blob_i8, hip_lib, monkeypatch):
+    """more workgroups than CUs: the int8 engine switches to its 128-VGPR variants (two workgroups per CU).  Same
+    arithmetic, other register allocation: bit-exact against the oracle; FAST results equal the one-workgroup variant's."""
+    T = 6
+    feats = distinct_feats(70000, n, T)
+    want = orc.synthesize_many(blob_i8, feats)
+    b = api.LPCNetBatch(n, blob_i8)
+    b.streams_per_workgroup = S
+    got = b.synthesize(feats)
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+    b.reset()
+    b.set_fast(True)
+    b.streams_per_workgroup = S
+    fast_packed = b.synthesize(feats)
+    b.close()
+    monkeypatch.setenv("LPCNET_HIP_PACK2", "0")
+    b = api.LPCNetBatch(n, blob_i8)
+    b.set_fast(True)
+    b.streams_per_workgroup = S
+    assert np.array_equal(b.synthesize(feats), fast_packed)
+    b.close()
+
+
 def test_1024_distinct_streams_full_occupancy(blob_f32, hip_lib):
     """BASELINE config 2 shape: 1024 DISTINCT streams, one workgroup of four per CU, all 1024 compared with the oracle."""
     n, T = 1024, 24

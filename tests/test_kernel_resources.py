@@ -16,7 +16,7 @@ def rows(tmp_path_factory):
     import kernel_resources as kr
     path = str(tmp_path_factory.mktemp("asm") / "sample_s4.s")
     kr.compile_asm(4, path)                                 # ~1 minute: every S = 4 variant, device code only
-    return {(r["NW"], r["int8"], r["fast"]): r for r in kr.analyse(path)}
+    return {(r["NW"], r["int8"], r["fast"]): r for r in kr.analyse(path) if not r["pack2"]}
 
 
 def test_no_scratch_access_inside_the_sample_loop(rows):
@@ -31,6 +31,17 @@ def test_no_scratch_access_inside_the_sample_loop(rows):
         assert rows[(nw, True, False)]["vgpr_spill"] == 0 and rows[(nw, True, False)]["scratch_bytes"] == 0
     # the benchmarked fp32 variant: its spills (frame-loop invariants) stay bounded
     assert rows[(30, False, False)]["vgpr_spill"] <= 16
+
+
+def test_two_workgroups_per_cu_variants_stay_out_of_scratch_in_the_loop(tmp_path_factory):
+    """the 128-VGPR int8 variants (S <= 2, 32 items per lane): spills allowed outside, none inside the sample loop"""
+    import kernel_resources as kr
+    path = str(tmp_path_factory.mktemp("asm2") / "sample_s2.s")
+    kr.compile_asm(2, path)
+    packed = [r for r in kr.analyse(path) if r["pack2"]]
+    assert len(packed) == 2                                 # PARITY and FAST
+    for r in packed:
+        assert r["int8"] and r["NW"] == 32 and r["vgpr"] <= 128 and r["scratch_insts_in_sample_loop"] == 0, r
 
 
 def test_fast_fmac_dpp_hazards(rows):

@@ -1,15 +1,9 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-python -m pytest tests/test_gpu_parity.py -x -q -k "int8" 2>&1 | tail -3
-for spw in 1 2 4; do
-python bench.py --steps 5 --warmup 2 --int8 --spw $spw --no-cpu-baseline > gpurun_out/b8_i8_s$spw.json 2> gpurun_out/b8.err
+python -m pytest tests/test_gpu_wide.py -x -q -k "two_workgroups" 2>&1 | tail -4
+for fl in "" "--fast"; do for cfg in "1024 0" "2048 0" "2048 4" "4096 4" "4096 2" "8192 4"; do set -- $cfg
+python bench.py --steps 3 --warmup 1 --int8 $fl --streams $1 --spw $2 --no-cpu-baseline --check-streams 0 > gpurun_out/b9.json 2> gpurun_out/b9.err
 python -c "
 import json,sys
-d=json.load(open('gpurun_out/b8_i8_s$spw.json'))
-print('int8 parity spw $spw', d['value']/1e6, d['ms_per_step'], d['roofline']['launch_ms'], d.get('parity_checked'))
-"; done
-python bench.py --steps 5 --warmup 2 --int8 --fast --no-cpu-baseline > gpurun_out/b8_i8_fast_auto.json 2> gpurun_out/b8.err
-python -c "
-import json,sys
-d=json.load(open('gpurun_out/b8_i8_fast_auto.json'))
-print('int8 fast auto', d['value']/1e6, d['ms_per_step'], d['config']['streams_per_workgroup'])
-"
+d=json.load(open('gpurun_out/b9.json'))
+print('int8 $fl streams $1 spw $2 -> S=%d: %.1f M  step %.2f ms' % (d['config']['streams_per_workgroup'], d['value']/1e6, d['ms_per_step']))
+"; done; done

@@ -29,8 +29,9 @@ def compile_asm(s_value, out_path):
 
 
 def demangle(name):
-    m = re.match(r"_ZN4lpcn13sample_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)EEE", name)
-    return None if not m else dict(S=int(m.group(1)), NW=int(m.group(2)), int8=bool(int(m.group(3))), fast=bool(int(m.group(4))))
+    m = re.match(r"_ZN4lpcn13sample_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)EEE", name)
+    return None if not m else dict(S=int(m.group(1)), NW=int(m.group(2)), int8=bool(int(m.group(3))), fast=bool(int(m.group(4))),
+                                   pack2=bool(int(m.group(5))))
 
 
 def analyse(asm_path):
@@ -96,7 +97,7 @@ def analyse(asm_path):
         rec = dict(name=name, **info, **meta.get(name, {}), scratch_insts=total, scratch_insts_in_sample_loop=in_loop, sample_loop_asm_lines=loop_lines,
                    fmac_dpp=sum(1 for i in insts if i.startswith("v_fmac_f32_dpp")), dpp_hazard_violations=dpp_viol)
         out.append(rec)
-    return sorted(out, key=lambda r: (r["S"], r["int8"], r["fast"], r["NW"]))
+    return sorted(out, key=lambda r: (r["S"], r["int8"], r["fast"], r["pack2"], r["NW"]))
 
 
 def main():
@@ -114,9 +115,9 @@ def main():
         print(json.dumps(rows, indent=1))
         return
     print(f"# {path}")
-    print("S NW int8 fast | vgpr sgpr vgpr_spill sgpr_spill scratch_B | scratch insts: total / in sample loop (loop asm lines)")
+    print("S NW int8 fast (+ = two workgroups per CU) | vgpr sgpr vgpr_spill sgpr_spill scratch_B | scratch insts: total / in sample loop (loop asm lines)")
     for r in rows:
-        print(f"{r['S']} {r['NW']:2d} {int(r['int8'])}    {int(r['fast'])}    | {r.get('vgpr', -1):4d} {r.get('sgpr', -1):4d} {r.get('vgpr_spill', -1):6d} {r.get('sgpr_spill', -1):10d} "
+        print(f"{r['S']} {r['NW']:2d} {int(r['int8'])}    {int(r['fast'])}{'+' if r['pack2'] else ' '}   | {r.get('vgpr', -1):4d} {r.get('sgpr', -1):4d} {r.get('vgpr_spill', -1):6d} {r.get('sgpr_spill', -1):10d} "
               f"{r.get('scratch_bytes', -1):9d} | {r['scratch_insts']:3d} / {r['scratch_insts_in_sample_loop']} ({r['sample_loop_asm_lines']})"
               + (f" | v_fmac_f32_dpp {r['fmac_dpp']}, hazard violations {r['dpp_hazard_violations']}" if r['fmac_dpp'] else ""))
 
