@@ -294,7 +294,7 @@ def main():
                                                               "frac": traffic / (ms_sample * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                                               "note": "measured PMC traffic per launch / live launch time: HBM is not a bound of this kernel"}},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:             # (reported at N = 1 only: the other ranks would wait for it)
             try:
                 out["cpu_baseline"] = cpu_baseline(a.int8)
             except Exception as e:  # the baseline must never take the GPU number down with it

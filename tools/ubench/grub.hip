@@ -7,7 +7,8 @@ template <int SEL> __device__ __forceinline__ float qb(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SEL * 0x55, 0xf, 0xf, true));
 }
 #define SB __builtin_amdgcn_sched_barrier(0)
-// MODE 0: loads + chain, 1: chain only (weights constant), 2: loads only, 3: chain without DPP, 4: adds only
+// MODE 0: loads + chain, 1: chain only (weights constant), 2: loads only, 3: chain without DPP, 4: adds only,
+// 5: loads + chain without DPP (the state operand as a plain register / SGPR: what an s_load-fed GRU-B would cost)
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float *out, unsigned long long *clk, int nblk, int active_waves)
 {
@@ -27,14 +28,14 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *clk, in
         for (int b = 0; b < nblk; b += 4) {
 #define STEP(WL, OFF, WN, K)                                                                    \
             {                                                                                   \
-                if (MODE == 0 || MODE == 2) WL = wp[OFF];                                       \
+                if (MODE == 0 || MODE == 2 || MODE == 5) WL = wp[OFF];                                       \
                 SB;                                                                             \
                 if (MODE != 2) {                                                                \
                     float t0_, t1_, t2_, t3_;                                                   \
-                    z = z + p0; SB; if (MODE == 4) t0_ = p0; else if (MODE == 3) t0_ = WN.x * h.x; else t0_ = WN.x * qb<K>(h.x); SB; \
-                    z = z + p1; SB; if (MODE == 4) t1_ = p1; else if (MODE == 3) t1_ = WN.y * h.y; else t1_ = WN.y * qb<K>(h.y); SB; \
-                    z = z + p2; SB; if (MODE == 4) t2_ = p2; else if (MODE == 3) t2_ = WN.z * h.z; else t2_ = WN.z * qb<K>(h.z); SB; \
-                    z = z + p3; SB; if (MODE == 4) t3_ = p3; else if (MODE == 3) t3_ = WN.w * h.w; else t3_ = WN.w * qb<K>(h.w); SB; \
+                    z = z + p0; SB; if (MODE == 4) t0_ = p0; else if (MODE == 3 || MODE == 5) t0_ = WN.x * h.x; else t0_ = WN.x * qb<K>(h.x); SB; \
+                    z = z + p1; SB; if (MODE == 4) t1_ = p1; else if (MODE == 3 || MODE == 5) t1_ = WN.y * h.y; else t1_ = WN.y * qb<K>(h.y); SB; \
+                    z = z + p2; SB; if (MODE == 4) t2_ = p2; else if (MODE == 3 || MODE == 5) t2_ = WN.z * h.z; else t2_ = WN.z * qb<K>(h.z); SB; \
+                    z = z + p3; SB; if (MODE == 4) t3_ = p3; else if (MODE == 3 || MODE == 5) t3_ = WN.w * h.w; else t3_ = WN.w * qb<K>(h.w); SB; \
                     p0 = t0_; p1 = t1_; p2 = t2_; p3 = t3_;                                     \
                 } else { asm volatile("" :: "v"(WL.x), "v"(WL.w)); }                            \
             }
@@ -72,6 +73,7 @@ int main()
         run("loads only", k<2>, waves);
         run("plain mul chain only", k<3>, waves);
         run("adds only", k<4>, waves);
+        run("loads + plain mul chain", k<5>, waves);
     }
     return 0;
 }
