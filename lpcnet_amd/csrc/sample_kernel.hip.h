@@ -685,13 +685,17 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // poll for the indices at item JG, issue the gathers, and resolve the gather-dependent
             // start values at item JSTAR (<= their first slot boundary).  The other waves wait for
             // the indices and resolve everything up front.  jmode is wave-uniform.
-            constexpr int JG = I8 ? 8 : 4, JSTAR = 18;
+            // JSTAR is the largest of 10 / 14 / 18 that does not exceed the first slot's length (wave-uniform, fixed per launch:
+            // a handful of possible positions keeps the resolve code from being inlined at every item of the chain)
+            constexpr int JG = 8, JSTAR_MAX = 18, JSTAR_MIN = I8 ? 18 : 10;   // (JG: the leader publishes ~2 k clk after the tree barrier = ~8 items)
+            int jstar = b1 >= 18 ? 18 : (b1 >= 14 ? 14 : 10);
+            LPCN_REMAT_S(jstar);
             // skip2: this wave already finished its last slot for this sample while GRU-B of the previous
             // sample was running (see P3): its items end at b2 and slot 2 is neither parked nor stored again
             const bool skip2 = early_done;
             early_done = false;
             const int jend = skip2 ? b2 : b3;
-            const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR) ? 1 : 0);
+            const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR_MIN) ? 1 : 0);
             if (jmode == 0) {
                 row_pre(0, 0); row_pre(1, 1); row_pre(2, 2);
                 wait_indices();
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // All tests below are wave-uniform scalar branches.  A taken branch costs ~35 clk of refetch, so the
             // common case (an ordinary item) must fall through every one of them: hence the expectations.
             auto item = [&](const int j) -> bool {           // false: this wave has no more items
-                if (j == JSTAR) {
+                if ((j == 10 || j == 14 || j == 18) && j >= JSTAR_MIN && j <= JSTAR_MAX && __builtin_expect(j == jstar, 0)) {
                     if (jmode) {
                         row_init(1, 0, false);
                         if (has2) { row_init(2, 1, false, !skip2); gather(0, 0); }     // (two-slot waves already hold slot 0's rows in set 1)
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 return true;
             };
 #pragma unroll
-            for (int j = 0; j < JG && j < NW; ++j) item(j);  // (no wave ends before JG: jmode needs b1 >= JSTAR, others just fall through)
+            for (int j = 0; j < JG && j < NW; ++j) item(j);  // (no wave ends before JG: jmode needs b1 >= JSTAR_MIN > JG, others just fall through)
             if (jmode) {                                     // between two fully unrolled halves
                 row_pre(1, 1); row_pre(2, 2);
                 wait_indices();
