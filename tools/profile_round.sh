@@ -22,4 +22,9 @@ for fl in f32 i8; do
 done
 python tools/profile_sq.py --tag r02 > $OUT/sq_f32.log 2>&1
 python tools/profile_sq.py --int8 --tag r02 > $OUT/sq_i8.log 2>&1
+# in-kernel s_memtime phase tables (profiling build of the library: python -m lpcnet_amd.build --prof)
+if [ -f lpcnet_amd/liblpcnet_hip_prof.so ]; then
+  LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32.log 2>&1
+  LPCN_FLAVOUR=int8 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1024:2 > $OUT/phase_i8.log 2>&1
+fi
 find $OUT -name "*.csv" | head -40

@@ -53,4 +53,11 @@ for fl, suffix in (("f32", ""), ("i8", "_int8")):
     b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
     if os.path.exists(b):
         shutil.copy(b, os.path.join(DST, f"{RND}_sq_counters{suffix}.csv"))
+ph = [os.path.join(SRC, f) for f in ("phase_f32.log", "phase_i8.log") if os.path.exists(os.path.join(SRC, f))]
+if ph:
+    with open(os.path.join(DST, f"{RND}_phase_clocks.txt"), "w") as o:
+        o.write("# in-kernel s_memtime phase table (profiling build: python -m lpcnet_amd.build --prof; LPCNET_HIP_LIB=.../liblpcnet_hip_prof.so\n"
+                "# python tests/tools/gpu_sweep.py 22 1024:4), shader clocks per sample step, workgroup 0; the instrumentation itself costs a few %\n")
+        for f in ph:
+            o.write(open(f).read())
 print(sorted(os.listdir(DST)))
