@@ -247,6 +247,21 @@ template <bool I8, bool FAST> __device__ __forceinline__ float acc_final(float a
     else return a;
 }
 
+// Activations.  PARITY: the reference's generic-C table tanh (src/vec.h:82-104), one LDS lookup each.  FAST: the hardware
+// exponential and reciprocal -- tanh(x) = 1 - 2/(2^(2x log2 e) + 1), sigmoid(x) = 1/(1 + 2^(-x log2 e)); like the reference's
+// AVX2 build, which also replaces the table by an approximation of its own (src/vec_avx.h:393-440), accurate to a few 1e-7
+// where the table version is accurate to ~1e-5.  Saturates correctly: 2^(+big) = inf -> 1, 2^(-big) = 0 -> -1.
+template <bool FAST> __device__ __forceinline__ float act_tanh(const float x, const float *tab)
+{
+    if constexpr (FAST) return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390082f) + 1.f);
+    else return lpcn_tanh(x, tab);
+}
+template <bool FAST> __device__ __forceinline__ float act_sigmoid(const float x, const float *tab)
+{
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.442695041f));
+    else return lpcn_sigmoid(x, tab);
+}
+
 // FAST = the arithmetic of the reference's SIMD builds instead of its generic-C order: fused multiply-add for float
 // blobs (src/vec_avx.h:790-858 _mm256_fmadd_ps), int32 block accumulation for int8 blobs (see acc_start).  Results are
 // no longer bit-identical to the generic-C build; tests/test_gpu_fast.py bounds the deviation teacher-forced.
@@ -822,14 +837,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     hold[q] = sm_hT[ic];
                 }
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) { z[q] = lpcn_sigmoid(z[q], sm_tansig); rg[q] = lpcn_sigmoid(rg[q], sm_tansig); }
+                for (int q = 0; q < NQ; ++q) { z[q] = act_sigmoid<FAST>(z[q], sm_tansig); rg[q] = act_sigmoid<FAST>(rg[q], sm_tansig); }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int i = tid + q * LPCN_WG_THREADS;
                     a[q] = a[q] * rg[q] + sm_inh[i < NI ? i : 0];
                 }
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) a[q] = lpcn_tanh(a[q], sm_tansig);
+                for (int q = 0; q < NQ; ++q) a[q] = act_tanh<FAST>(a[q], sm_tansig);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int i = tid + q * LPCN_WG_THREADS;
@@ -866,14 +881,55 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             const float fcb = as_global(Ap->fc_b)[chan * 256 + node], fcf = as_global(Ap->fc_f)[chan * 256 + node];
             LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
-            if (wave < S) {
+            // FAST, int8 blobs, dense input matrix: integer block sums are exact in any order, so the 96 input blocks of a
+            // stream are split over GB_W = 8/S waves (each reads 1/GB_W of the weights), the partial sums meet in LDS and
+            // the first wave of each stream's group runs the gate stage.  (PARITY keeps one wave per stream: a row's 384-term
+            // float sum has to stay in the reference's order.)
+            constexpr int GB_W = LPCN_WAVES / S;
+            bool gb_split = false;                           // wave-uniform
+            if constexpr (I8 && FAST) {
+                if (b_dense) {
+                    typedef int i4 __attribute__((ext_vector_type(4)));
+                    constexpr int QP = 24 / GB_W;            // quads of 4 blocks per wave: 3, 6 or 12
+                    const int s2 = wave / GB_W, part = wave - s2 * GB_W;
+                    const int r = lane < RB ? lane : RB - 1;
+                    const i4 *wq = (const i4 *)(smem + L::bw) + (sm_bstart[r >> 3] >> 2) * 8 + (r & 7) + part * QP * 8;
+                    const i4 *xq4 = (const i4 *)(smem + L::xqT + s2 * 384) + part * QP;
+                    int z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+#pragma unroll
+                    for (int q = 0; q < QP; ++q) {
+                        const i4 w4 = wq[q * 8], x4 = xq4[q];
+                        z0 = __builtin_amdgcn_sdot4(w4[0], x4[0], z0, false);
+                        z1 = __builtin_amdgcn_sdot4(w4[1], x4[1], z1, false);
+                        z2 = __builtin_amdgcn_sdot4(w4[2], x4[2], z2, false);
+                        z3 = __builtin_amdgcn_sdot4(w4[3], x4[3], z3, false);
+                    }
+                    ((int *)sm_pre)[wave * 64 + lane] = (z0 + z1) + (z2 + z3);      // (sm_pre is idle in this phase: int8 blobs have no early slots)
+                    __syncthreads();
+                    gb_split = true;
+                }
+            }
+            if (gb_split ? (wave % GB_W == 0) : (wave < S)) {
                 __builtin_amdgcn_s_setprio(3);                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
-                const int s = wave;
+                const int s = gb_split ? wave / GB_W : wave;
                 const int r = lane < RB ? lane : RB - 1;
                 const int g = r >> 3, ri = r & 7;
                 float zrh = sm_bbias[r] + sm_condb[s * RB + r];               // src/nnet.c:351
                 float rec = sm_bbias[RB + r];
                 if constexpr (I8 && FAST) {
+                  if (gb_split) {
+                    typedef int i4 __attribute__((ext_vector_type(4)));
+                    int rsum = (int)__builtin_rintf(rec * QS), zsum = (int)__builtin_rintf(zrh * QS);     // src/vec_avx.h:703-705
+                    const i4 wr = ((const i4 *)(smem + L::brec))[r];
+                    const i4 hb = *(const i4 *)(smem + L::hBq + s * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rsum = __builtin_amdgcn_sdot4(wr[k], hb[k], rsum, false);
+#pragma unroll
+                    for (int k = 0; k < GB_W; ++k) zsum += ((const int *)sm_pre)[(s * GB_W + k) * 64 + lane];
+                    rec = (float)rsum * QS1;
+                    zrh = (float)zsum * QS1;
+                    (void)g; (void)ri;
+                  } else {
                     // int32 accumulation like the reference's AVX2 int8 build (src/vec_avx.h:690-750): start values rounded
                     // to the 1/(128*127) grid, exact block sums; integer addition is associative, so the four blocks of a
                     // 16-byte weight read feed four independent chains
@@ -911,6 +967,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         }
                     }
                     zrh = (float)((z0 + z1) + (z2 + z3)) * QS1;
+                  }
                 } else if constexpr (I8) {
                     typedef int i4 __attribute__((ext_vector_type(4)));
                     zrh = zrh * QS;
@@ -1038,9 +1095,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 LPCN_PROF(8);      // GRU-B input mat-vec
                 __builtin_amdgcn_s_setprio(0);
                 // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
-                const float sg = lpcn_sigmoid(zrh + rec, sm_tansig);
+                const float sg = act_sigmoid<FAST>(zrh + rec, sm_tansig);
                 const float r_gate = __shfl(sg, 16 + (lane & 15));
-                const float hc = lpcn_tanh(zrh + rec * r_gate, sm_tansig);
+                const float hc = act_tanh<FAST>(zrh + rec * r_gate, sm_tansig);
                 const float hc_i = __shfl(hc, 32 + (lane & 15));
                 if (lane < NB) {
                     const float hold = sm_hB[s * NB + lane];
@@ -1094,7 +1151,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         if constexpr (FAST) sum = __builtin_fmaf(fcw[j], sm_hB[s * NB + j], sum);
                         else sum = sum + fcw[j] * sm_hB[s * NB + j];
                     }
-                    const float v = fcf * lpcn_tanh(sum, sm_tansig);
+                    const float v = fcf * act_tanh<FAST>(sum, sm_tansig);
                     // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
                     const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
                     const float logit = v + vo;                                     // sum1 += sum2
