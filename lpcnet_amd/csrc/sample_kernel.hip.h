@@ -618,12 +618,27 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 const float4 hv = hq[j % (PF + 1)];
                 const float hk[4] = {hv.x, hv.y, hv.z, hv.w};
                 const float wk[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+                if constexpr (FAST && S >= 2) {
+                    // FAST: the quad broadcast as a 4x4 outer product on the matrix pipe.  v_mfma_f32_4x4x1_16B_f32 gives lane j
+                    // of a quad, in register k, A(lane k) * B(lane j) + C: with A = this lane's state value (lane k fetched
+                    // stream k's block), B = this lane's weight and C = the running sums, ONE instruction does the fused
+                    // multiply-adds of a column for all four streams (tools/ubench/mfma4.hip: 61 clk per item against
+                    // 155 for 16 DPP multiplies + 16 adds).  With C = -0.0 the result is the separately rounded product
+                    // bit for bit, so PARITY could use it as a multiplier too -- measured: no faster in this kernel (two
+                    // waves per SIMD contend for the matrix pipe, and the item loop is bound by its LDS read and control).
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    f4 av;
+                    av[0] = acc[0]; av[1] = acc[1]; av[2] = S == 4 ? acc[2] : 0.f; av[3] = S == 4 ? acc[3] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) av = __builtin_amdgcn_mfma_f32_4x4x1f32(hk[c], wk[c], av, 0, 0, 0);
+                    acc[0] = av[0]; acc[1] = av[1];
+                    if constexpr (S == 4) { acc[2] = av[2]; acc[3] = av[3]; }
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if constexpr (FAST) {                    // fused multiply-add (v_fmac_f32 with the DPP operand folded in)
+                    if constexpr (FAST) {
                         if constexpr (S == 1) acc[0] = __builtin_fmaf(wk[c], hk[c], acc[0]);
-                        if constexpr (S >= 2) { acc[0] = fmac_quad<0>(acc[0], wk[c], hk[c]); acc[1] = fmac_quad<1>(acc[1], wk[c], hk[c]); }
-                        if constexpr (S == 4) { acc[2] = fmac_quad<2>(acc[2], wk[c], hk[c]); acc[3] = fmac_quad<3>(acc[3], wk[c], hk[c]); }
+                        // (S >= 2: all four columns at once below, on the matrix pipe)
                     } else if constexpr (S == 1) {
                         acc[0] = acc[0] + wk[c] * hk[c];
                     } else if constexpr (S == 2) {
@@ -909,13 +924,54 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     gb_split = true;
                 }
             }
-            if (gb_split ? (wave % GB_W == 0) : (wave < S)) {
+            // FAST, float blobs, dense input matrix: wave s + 4 (it shares stream s's SIMD) takes the last quads of the 96 input
+            // blocks once its early GRU-A slot is done; fused multiply-adds into four independent sums per part (the order of
+            // a row's sum is free in FAST), the parts meet in LDS (sm_inh is idle in this phase).  The helper's early slot
+            // (e items of ~80 clk on the matrix pipe) comes first, a quad costs ~290 clk here: both finish together with
+            // gb_qa = (24 + e * 0.28) / 2 quads on the stream's own wave.
+            const bool gb_fsplit = FAST && !I8 && b_dense && S <= LPCN_WAVES / 2;
+            int gb_qa = 24;
+            if constexpr (FAST && !I8) {
+                const int hw = wave < LPCN_WAVES / 2 ? wave + LPCN_WAVES / 2 : wave;       // the helper wave of this pair
+                const auto *bd = as_global(Ap->a_bound) + hw * 4;
+                const int e = (hw >= S && as_global(Ap->a_allh)[hw * 3 + 2] != 0) ? bd[3] - bd[2] : 0;
+                gb_qa = __builtin_amdgcn_readfirstlane((24 + (9 * e) / 32) / 2);
+                gb_qa = gb_qa > 24 ? 24 : gb_qa;
+            }
+            auto gb_part_fast = [&](const int gs_, const int q_lo, const int q_hi) -> float {
+                const int r_ = lane < RB ? lane : RB - 1;
+                const int bbeg_ = sm_bstart[r_ >> 3];
+                const unsigned char *wptr = smem + L::bw + ((bbeg_ + 4 * q_lo) * 8 + (r_ & 7)) * 16;
+                const unsigned char *hbase = smem + L::hA + gs_ * 16;
+                const unsigned short *offk = sm_boff + bbeg_ + (lane & 3);
+                auto ldw = [&](int byte_off) { return *(const float4 *)(wptr + byte_off); };
+                auto ldh = [&](int q) { return *(const float4 *)(hbase + offk[4 * q]); };
+                float4 wr0 = ldw(0), wr1 = ldw(128), wr2 = ldw(256), wr3;
+                float4 hq = ldh(q_lo), hn;
+                float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+                for (int q = q_lo; q < q_hi; ++q) {          // (reads one quad / three blocks past the end: valid, unused LDS data)
+                    wr3 = ldw(384); hn = ldh(q + 1);
+                    z0 = fmac_quad<0>(z0, wr0.x, hq.x); z1 = fmac_quad<0>(z1, wr0.y, hq.y); z2 = fmac_quad<0>(z2, wr0.z, hq.z); z3 = fmac_quad<0>(z3, wr0.w, hq.w);
+                    wr0 = ldw(512);
+                    z0 = fmac_quad<1>(z0, wr1.x, hq.x); z1 = fmac_quad<1>(z1, wr1.y, hq.y); z2 = fmac_quad<1>(z2, wr1.z, hq.z); z3 = fmac_quad<1>(z3, wr1.w, hq.w);
+                    wr1 = ldw(640);
+                    z0 = fmac_quad<2>(z0, wr2.x, hq.x); z1 = fmac_quad<2>(z1, wr2.y, hq.y); z2 = fmac_quad<2>(z2, wr2.z, hq.z); z3 = fmac_quad<2>(z3, wr2.w, hq.w);
+                    wr2 = ldw(768);
+                    z0 = fmac_quad<3>(z0, wr3.x, hq.x); z1 = fmac_quad<3>(z1, wr3.y, hq.y); z2 = fmac_quad<3>(z2, wr3.z, hq.z); z3 = fmac_quad<3>(z3, wr3.w, hq.w);
+                    hq = hn;
+                    wptr += 512;
+                }
+                return (z0 + z1) + (z2 + z3);
+            };
+            const bool gate_wave = gb_split ? (wave % GB_W == 0) : (wave < S);      // wave-uniform
+            float zrh = 0.f, rec = 0.f;
+            const int s = gb_split ? wave / GB_W : wave;     // (stream of a gate wave)
+            const int r = lane < RB ? lane : RB - 1;
+            if (gate_wave) {
                 __builtin_amdgcn_s_setprio(3);                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
-                const int s = gb_split ? wave / GB_W : wave;
-                const int r = lane < RB ? lane : RB - 1;
                 const int g = r >> 3, ri = r & 7;
-                float zrh = sm_bbias[r] + sm_condb[s * RB + r];               // src/nnet.c:351
-                float rec = sm_bbias[RB + r];
+                zrh = sm_bbias[r] + sm_condb[s * RB + r];                     // src/nnet.c:351
+                rec = sm_bbias[RB + r];
                 if constexpr (I8 && FAST) {
                   if (gb_split) {
                     typedef int i4 __attribute__((ext_vector_type(4)));
@@ -1039,6 +1095,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         }
                     }
                     zrh = zrh * QS1;
+                } else if (gb_fsplit) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) rec = __builtin_fmaf(sm_brec[j * RB + r], sm_hB[s * NB + j], rec);
+                    zrh = zrh + gb_part_fast(s, 0, gb_qa);
+                    (void)g; (void)ri;
                 } else {
                 // Each group's block list is padded to a multiple of 4 (zero weights) by the host.
                 // This phase runs one wave per SIMD, so latency must be hidden by software, and the
@@ -1094,19 +1155,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 LPCN_PROF(8);      // GRU-B input mat-vec
                 __builtin_amdgcn_s_setprio(0);
-                // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
-                const float sg = act_sigmoid<FAST>(zrh + rec, sm_tansig);
-                const float r_gate = __shfl(sg, 16 + (lane & 15));
-                const float hc = act_tanh<FAST>(zrh + rec * r_gate, sm_tansig);
-                const float hc_i = __shfl(hc, 32 + (lane & 15));
-                if (lane < NB) {
-                    const float hold = sm_hB[s * NB + lane];
-                    const float hnew = sg * hold + (1.f - sg) * hc_i;
-                    if ((live_mask >> s) & 1) {
-                        sm_hB[s * NB + lane] = hnew;
-                        if constexpr (I8) smem[L::hBq + s * NB + lane] = (unsigned char)quant_s8(hnew);
-                    }
-                }
             } else if (early_wave) {
                 // ---- GRU-A's last slot of the next sample (runs in the shadow of GRU-B): items [b2, b3)
                 {
@@ -1134,6 +1182,30 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 run_early(run_early, std::integral_constant<int, 0>{});
                 row_store(2);
                 early_done = true;
+            
+            }
+            if constexpr (FAST && !I8) {
+                if (gb_fsplit) {                             // (workgroup-uniform)
+                    if (wave >= LPCN_WAVES / 2 && wave - LPCN_WAVES / 2 < S)
+                        sm_inh[(wave - LPCN_WAVES / 2) * 64 + lane] = gb_part_fast(wave - LPCN_WAVES / 2, gb_qa, 24);
+                    __syncthreads();
+                    if (gate_wave) zrh = zrh + sm_inh[s * 64 + lane];
+                }
+            }
+            if (gate_wave) {
+                // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
+                const float sg = act_sigmoid<FAST>(zrh + rec, sm_tansig);
+                const float r_gate = __shfl(sg, 16 + (lane & 15));
+                const float hc = act_tanh<FAST>(zrh + rec * r_gate, sm_tansig);
+                const float hc_i = __shfl(hc, 32 + (lane & 15));
+                if (lane < NB) {
+                    const float hold = sm_hB[s * NB + lane];
+                    const float hnew = sg * hold + (1.f - sg) * hc_i;
+                    if ((live_mask >> s) & 1) {
+                        sm_hB[s * NB + lane] = hnew;
+                        if constexpr (I8) smem[L::hBq + s * NB + lane] = (unsigned char)quant_s8(hnew);
+                    }
+                }
             }
             __syncthreads();                                                   // B3
             LPCN_PROF(2);
