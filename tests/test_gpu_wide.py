@@ -84,6 +84,22 @@ def test_1024_distinct_streams_full_occupancy(blob_f32, hip_lib):
     b.close()
 
 
+@pytest.mark.parametrize("flavour", ["float", "int8"])
+def test_soak_1024_streams_two_seconds(flavour, hip_lib):
+    """3.2e7 samples through the barrier-free index hand-off at full occupancy: 1024 distinct streams x 200 frames in one
+    call (two 100-frame chunks); 64 streams spread over the workgroups (every position inside a workgroup) against the oracle"""
+    blob = synth.blob_bytes(synth.make_model(flavour=flavour))
+    n, T = 1024, 200
+    feats = distinct_feats(80000, n, T)
+    pick = np.array([(i * 16 + (i % 4)) % n for i in range(64)])
+    want = orc.synthesize_many(blob, feats[pick])
+    b = api.LPCNetBatch(n, blob)
+    got = b.synthesize(feats)
+    assert first_mismatch(got[pick], want) is None, first_mismatch(got[pick], want)
+    assert np.all(np.abs(got.astype(np.int32)).max(axis=1) > 0)
+    b.close()
+
+
 def test_ten_second_files_past_frame_count_saturation(blob_f32, hip_lib):
     """1010 frames per stream: frame_count saturates at 1000 (src/lpcnet.c:119), ten 100-frame chunks + a partial one."""
     n, T = 4, 1010
