@@ -58,6 +58,7 @@ struct lpcn_batch_dev {
     float *d_cond_a = nullptr, *d_cond_b = nullptr, *d_lpc = nullptr, *d_cond = nullptr;
     float *d_feat = nullptr;           // staging for host-pointer runs / decoded feature vectors
     float *d_vq_mem = nullptr;         // [n][18] VQ memory of the codec path (src/lpcnet_private.h:52)
+    float *d_hmir = nullptr;           // [stream slot][384] GRU-A state mirror read by GRU-B through the scalar cache (sample_kernel.hip.h: gb_scalar)
     unsigned char *d_packets = nullptr;
     size_t packets_cap = 0;
     short *d_pcm = nullptr;
@@ -340,6 +341,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
     AL(b->d_cond, sizeof(float) * (size_t)n * (max_chunk + 4) * LPCN_COND * 2);
     AL(b->d_args, sizeof(LpcnSampleArgs));
     AL(b->d_vq_mem, sizeof(float) * (size_t)n * LPCN_NB_BANDS);
+    AL(b->d_hmir, sizeof(float) * ((size_t)n + 4) * LPCN_N_A);       // workgroups x S slots: the last workgroup may be partly filled
 #undef AL
     for (auto &ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) return fail(LPCN_E_HIP);
     if (hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming) != hipSuccess) return fail(LPCN_E_HIP);
@@ -357,7 +359,7 @@ extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
     if (b->h_pin) (void)hipHostFree(b->h_pin);
     if (b->ev_last) (void)hipEventDestroy(b->ev_last);
     void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof,
-                    b->d_vq_mem, b->d_packets};
+                    b->d_vq_mem, b->d_packets, b->d_hmir};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : b->ev) if (ev) (void)hipEventDestroy(ev);
     delete b;
@@ -462,6 +464,8 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.fc_base = fc_from_frames ? b->d_fc_base : nullptr;
     a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
     a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
+    a.tune = getenv("LPCNET_HIP_TUNE") ? atoi(getenv("LPCNET_HIP_TUNE")) : 0;
+    a.hmir = getenv("LPCNET_HIP_SCALAR_GRUB") ? b->d_hmir : nullptr;         // (work in progress: opt-in until the row dealing follows the shorter GRU-B)
     HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
     const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0;
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);

@@ -70,6 +70,8 @@ struct LpcnSampleArgs {
     short *pcm;                                     // [stream] x pcm_stride samples, frame f at +f*160
     long long pcm_stride;
     lpcn_stream_state *state;                       // [stream]
+    int tune;                                       // experiment switches (tools; LPCNET_HIP_TUNE), 0 = product behaviour
+    float *hmir;                                    // [workgroup][S][384] L2-resident mirror of the GRU-A state for GRU-B's scalar loads (or NULL)
     float *dbg;                                     // optional per-sample trace (tests)
     unsigned long long *prof;                       // optional: [8] shader-clock totals per phase, workgroup 0 wave 0
 };
@@ -221,6 +223,14 @@ template <int J> __device__ __forceinline__ float lpc_chain(float r, float prod)
     else return r;
 }
 
+// ---- GRU-B input mat-vec with the state operand in SGPRs (PARITY, float blobs, dense input matrix) -----------------------
+// Every row of GRU-B multiplies the SAME 384 state values: a wave-uniform operand.  Instead of LDS reads + DPP quad
+// broadcasts (a DPP-operand instruction costs ~9 clk of issue, an LDS read ~30), the gate stage mirrors the new state into
+// an L2-resident buffer and the stream's GRU-B wave pulls it through the scalar cache: s_load_dwordx16 = 4 blocks, used as
+// SGPR-pair operands of v_pk_mul_f32 (two separately rounded products per instruction; tools/ubench/grub2.hip: 48 clk per
+// block against 77-83).  SMEM returns out of order, so every wait is lgkmcnt(0), and a scalar load must never be in flight
+// across an inline-asm boundary (the register allocator may spill or copy a tuple it believes defined): loads, waits and
+// consumers are ONE assembly block with its own registers, generated by tools/gen_grub_asm.py (grub_scalar_loop.inc).
 // PACK2 variants: the register allocation leaves room for 4 waves per SIMD (128 VGPRs per lane), i.e. TWO workgroups per
 // CU, which fill each other's barrier / latency bubbles (measured: a second resident workgroup slows the first by only
 // ~15 %).  Only the int8 kernels with <= 32 items per lane and S <= 2 get there without a scratch access inside the
@@ -345,6 +355,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     int b3 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 3]);   // this wave's item count
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
     const bool b_dense = Ap->b_dense != 0;
+    // PARITY, float blob, dense GRU-B input matrix: GRU-B takes the GRU-A state through scalar loads (see grub_scalar_loop.inc)
+    const bool gb_scalar = !I8 && !FAST && b_dense && Ap->hmir != nullptr;
     // bit k: this wave owns rows in slot k (wave-uniform)
     const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row[1] >= 0) != 0ull ? 2 : 0) |
                                                         (__ballot(row[2] >= 0) != 0ull ? 4 : 0));
@@ -479,7 +491,33 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (v != seq) __builtin_amdgcn_s_sleep(1);
         } while (v != seq);
     };
-    if (tid0 == 0) *(int *)(smem + L::flag) = 0;
+    // State mirror hand-off (gb_scalar): a wave's mirror stores are in L2 once its s_waitcnt vmcnt(0) returns; it then bumps an
+    // arrival counter in LDS, and a GRU-B wave starts its scalar loads when all eight waves of this sample have arrived.  The
+    // store round trip (~500 clk) is off the barrier path: GRU-B waves form the recurrent part first, the others go on.
+    int gbseq = 0;                                           // samples handed off so far (identical in every wave)
+    const uint32_t arrive_addr = flag_addr + 4;
+    auto mirror_arrive = [&]() {
+        // one lane bumps the counter; EXEC is narrowed INSIDE the statement: a compiler-visible `if (lane == 0)` next to the
+        // GRU-B assembly block (40 clobbered VGPRs) made hipcc 7.2 place its vacate copies inside the masked region
+        int one = 1;
+        unsigned long long ex;
+        asm volatile("s_waitcnt vmcnt(0)\n\t"
+                     "s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %1, %2\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(ex) : "v"(arrive_addr), "v"(one) : "memory");
+    };
+    auto mirror_wait = [&]() {
+        int v;
+        const int want = gbseq * LPCN_WAVES;
+        do {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(arrive_addr) : "memory");
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v != want) __builtin_amdgcn_s_sleep(1);
+        } while (v != want);
+    };
+    if (tid0 == 0) { *(int *)(smem + L::flag) = 0; *(int *)(smem + L::flag + 4) = 0; }
 
 #if LPCN_ENABLE_PROF      // per-phase shader-clock accounting (profiling builds only: it costs VGPRs)
     unsigned long long *const prof = Ap->prof;
@@ -874,10 +912,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                             smem[L::xqT + (s * 96 + (n >> 2)) * 4 + (n & 3)] = qv;
                         } else {
                             *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv;
+                            if constexpr (!FAST) {
+                                if (gb_scalar) as_global_rw(Ap->hmir)[((size_t)blockIdx.x * S + s) * NA + n] = hv;     // [stream][neuron]: one 64-byte line = 4 blocks
+                            }
                         }
                     }
                 }
             }
+            if (Ap->tune & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                                   // B2
             LPCN_PROF(1);
 
@@ -964,11 +1006,16 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 return (z0 + z1) + (z2 + z3);
             };
             const bool gate_wave = gb_split ? (wave % GB_W == 0) : (wave < S);      // wave-uniform
+            if constexpr (!I8 && !FAST) {
+                if (gb_scalar) { ++gbseq; if (!gate_wave && !(Ap->tune & 32)) mirror_arrive(); }
+            }
             float zrh = 0.f, rec = 0.f;
             const int s = gb_split ? wave / GB_W : wave;     // (stream of a gate wave)
             const int r = lane < RB ? lane : RB - 1;
             if (gate_wave) {
-                __builtin_amdgcn_s_setprio(3);                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
+                // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
+                if ((Ap->tune & 3) == 0) __builtin_amdgcn_s_setprio(3);
+                else if ((Ap->tune & 3) == 1) __builtin_amdgcn_s_setprio(1);
                 const int g = r >> 3, ri = r & 7;
                 zrh = sm_bbias[r] + sm_condb[s * RB + r];                     // src/nnet.c:351
                 rec = sm_bbias[RB + r];
@@ -1100,6 +1147,17 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     for (int j = 0; j < NB; ++j) rec = __builtin_fmaf(sm_brec[j * RB + r], sm_hB[s * NB + j], rec);
                     zrh = zrh + gb_part_fast(s, 0, gb_qa);
                     (void)g; (void)ri;
+                } else if (gb_scalar && !(Ap->tune & 16)) {
+                    // state through SGPRs: the whole 96-block loop is one hand-scheduled assembly block (tools/gen_grub_asm.py)
+                    const float *hb = Ap->hmir + ((size_t)blockIdx.x * S + s) * NA;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
+                    if (!(Ap->tune & 32)) mirror_arrive();
+                    if (!(Ap->tune & 8)) mirror_wait();
+                    uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::bw + (sm_bstart[g] * 8 + ri) * 16);   // this lane's row, block 0 of its group
+                    asm volatile(
+#include "grub_scalar_loop.inc"
+                        : [z] "+v"(zrh), [wp] "+v"(wp32) : [hb] "s"(hb) : LPCN_GRUB_SCALAR_CLOBBERS);
                 } else {
                 // Each group's block list is padded to a multiple of 4 (zero weights) by the host.
                 // This phase runs one wave per SIMD, so latency must be hidden by software, and the
@@ -1207,6 +1265,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                 }
             }
+            LPCN_PROF(11);     // GRU-B gates (gate waves) / early GRU-A slot (the others)
             __syncthreads();                                                   // B3
             LPCN_PROF(2);
 

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Generate lpcnet_amd/csrc/grub_scalar_loop.inc: the hand-scheduled GRU-B input mat-vec loop of the PARITY float kernel
+with the state operand in SGPRs (sample_kernel.hip.h, `gb_scalar`).
+
+    python tools/gen_grub_asm.py > lpcnet_amd/csrc/grub_scalar_loop.inc
+
+Why one assembly block: the state arrives through s_load_dwordx16 (SMEM returns out of order -> every wait is lgkmcnt(0)),
+and a scalar load must never be in flight across an inline-asm boundary -- the register allocator may spill or copy an
+SGPR tuple it believes defined while the load is still filling it.  So loads, waits and consumers live in ONE block that
+names its registers itself (declared as clobbers).
+
+Per output row (lane) and stream: zrh += sum over 96 blocks x 4 columns of w * h, every product and every sum rounded
+separately, in block order / column order (src/vec.h:355-401).  The chain of 384 dependent v_add_f32 is the floor
+(~6.6 clk each); everything else sits in its shadow:
+  * products of block b+1 (2 v_pk_mul_f32: SGPR pair x VGPR pair) are formed during the adds of block b;
+  * a group = 4 blocks = one s_load_dwordx16 (64 B of state) + four ds_read_b128 (the lane's weights); two buffers;
+    the loads of group g+2 are issued at block 3 of group g, right after the ONE s_waitcnt lgkmcnt(0) of the group,
+    which at that point guarantees group g+1 -- a full group (~110 clk) of lookahead for both LDS and scalar cache.
+Register use (fixed, clobbered): s[36:51] / s[52:67] state tuples, s68/s69 offsets, s70 trip counter, s71 touch target;
+v[216:231] / v[232:247] weights, v[248:251] / v[252:255] products.
+"""
+GROUPS = 24            # 96 blocks
+GROUPS_PER_TRIP = 4    # 6 trips; the taken branch at the end of a trip costs ~35 clk
+T = {0: 36, 1: 52}     # SGPR tuple base per buffer
+W = {0: 216, 1: 232}   # VGPR weight base per buffer (4 blocks x float4)
+P = {0: 248, 1: 252}   # product registers (alternate per block)
+OFF, OFFC, CNT, DUMMY = 68, 69, 70, 71
+
+
+def pk_mul(dst, sreg, vreg):
+    return f"v_pk_mul_f32 v[{dst}:{dst + 1}], s[{sreg}:{sreg + 1}], v[{vreg}:{vreg + 1}]"
+
+
+def products(pbuf, tbuf, blk):
+    """products of block `blk` (0..3) of the group in buffer tbuf -> product set pbuf"""
+    return [pk_mul(P[pbuf], T[tbuf] + 4 * blk, W[tbuf] + 4 * blk), pk_mul(P[pbuf] + 2, T[tbuf] + 4 * blk + 2, W[tbuf] + 4 * blk + 2)]
+
+
+def adds(pbuf):
+    return [f"v_add_f32 %[z], %[z], v{P[pbuf] + k}" for k in range(4)]
+
+
+def interleave(a, fill):
+    """one filler after each dependent add (the add's latency is the slot)"""
+    out = []
+    for i, x in enumerate(a):
+        out.append(x)
+        if i < len(fill):
+            out.append(fill[i])
+    out += fill[len(a):]
+    return out
+
+
+def group(k, buf, lds_off_next2):
+    """group in buffer `buf`; entering: product set 0 holds block 0's products.  lds_off_next2 = byte offset (from %[wp]) of the
+    weights of the group two ahead."""
+    o = 1 - buf
+    code = []
+    # blocks 0..2: adds of block b, products of block b+1 (same group)
+    pset = 0
+    for b in range(3):
+        code += interleave(adds(pset), products(1 - pset, buf, b + 1))
+        pset = 1 - pset
+    # block 3: the group's one wait; products of the NEXT group's block 0; loads of the group two ahead into this group's buffers
+    loads = [f"s_add_u32 s{OFF}, s{OFF}, 64",
+             f"s_min_u32 s{OFFC}, s{OFF}, 1472",
+             f"s_load_dwordx16 s[{T[buf]}:{T[buf] + 15}], %[hb], s{OFFC}"]
+    loads += [f"ds_read_b128 v[{W[buf] + 4 * j}:{W[buf] + 4 * j + 3}], %[wp] offset:{lds_off_next2 + 128 * j}" for j in range(4)]
+    a = adds(pset)
+    nxt = products(1 - pset, o, 0)
+    code.append("s_waitcnt lgkmcnt(0)")
+    code += [a[0], nxt[0], a[1], nxt[1], loads[0], loads[1], loads[2], a[2], loads[3], loads[4], a[3], loads[5], loads[6]]
+    assert pset == 1            # after three alternations block 3's products sit in set 1, the next group's block 0 in set 0
+    return code
+
+
+def main():
+    lines = []
+    # prologue: groups 0 and 1 -> buffers 0 and 1, products of (group 0, block 0)
+    # The scalar cache still holds the previous sample's copy of these addresses: drop it, then touch all 24 lines of the
+    # stream at once so that the L2 round trips (~280 clk each) overlap; the touches land in a register of this block
+    # (a load must not be in flight into a register the compiler may reuse).
+    lines += ["s_dcache_inv",
+              f"s_mov_b32 s{OFF}, 64",
+              f"s_mov_b32 s{CNT}, {GROUPS // GROUPS_PER_TRIP}",
+              f"s_load_dwordx16 s[{T[0]}:{T[0] + 15}], %[hb], 0x0"]
+    lines += [f"s_load_dwordx16 s[{T[1]}:{T[1] + 15}], %[hb], 0x40"]
+    lines += [f"s_load_dword s{DUMMY}, %[hb], {hex(64 * k)}" for k in range(2, GROUPS)]
+    lines += [f"ds_read_b128 v[{W[0] + 4 * j}:{W[0] + 4 * j + 3}], %[wp] offset:{128 * j}" for j in range(4)]
+    lines += [f"ds_read_b128 v[{W[1] + 4 * j}:{W[1] + 4 * j + 3}], %[wp] offset:{512 + 128 * j}" for j in range(4)]
+    lines += ["s_waitcnt lgkmcnt(0)"] + products(0, 0, 0)
+    lines += ["1:"]
+    for k in range(GROUPS_PER_TRIP):
+        lines += group(k, k & 1, (k + 2) * 512)
+    lines += [f"v_add_u32 %[wp], {GROUPS_PER_TRIP * 512}, %[wp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py -- do not edit")
+    print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hb] state mirror (SGPR pair)")
+    clob = [f"s{i}" for i in range(36, 72)] + [f"v{i}" for i in range(216, 256)]
+    print("#undef LPCN_GRUB_SCALAR_CLOBBERS")
+    print("#define LPCN_GRUB_SCALAR_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
+if __name__ == "__main__":
+    main()
