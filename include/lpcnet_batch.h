@@ -94,7 +94,8 @@ LPCNET_EXPORT int lpcnet_batch_run_tail(LPCNetBatch *b, const float *cond_a, con
                                         short *pcm, int n_frames, int preload);
 LPCNET_EXPORT int lpcnet_batch_run_frames(LPCNetBatch *b, const float *features, int feat_stride,
                                           float *cond_a, float *cond_b, float *lpc, int n_frames);
-/* tools: GRU-A row dealing of a blob (out[57]: items per lane, then per wave bound[4] + candidate-only flags[3]) */
+/* tools: GRU-A row dealing of a blob (out[65]: items per lane, then per wave bound[4] + candidate-only flags[3], then
+ * per wave the number of early head items of slot 0) */
 LPCNET_EXPORT int lpcnet_hip_model_layout(const unsigned char *data, int len, int *out);
 /* the engine's own correctly rounded 10^x of the LPC path (pow(10.f, x) of src/freq.c:317) evaluated on the device */
 LPCNET_EXPORT int lpcnet_hip_exp10_device(const float *x, double *out, int n);

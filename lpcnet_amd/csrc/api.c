@@ -871,7 +871,8 @@ int lpcnet_batch_debug_trace(LPCNetBatch *b, int n_samples, float *host_out) { N
 int lpcnet_batch_profile(LPCNetBatch *b, unsigned long long *out) { NEED_MODEL(b); FWD(lpcn_batch_dev_profile(b->sh[0].dev, out)); }
 
 /* tools: how GRU-A's rows were dealt to the 8 waves of the sample kernel: out[0] = items per lane, then per wave
- * {bound[0..3], allh[0..2]} (item index where each slot starts / slot holds only candidate rows) */
+ * {bound[0..3], allh[0..2]} (item index where each slot starts / slot holds only candidate rows), then out[57 + wave] =
+ * items of slot 0's chains computed one sample ahead (stored end-aligned, [nw - head, nw)) */
 int lpcnet_hip_model_layout(const unsigned char *data, int len, int *out)
 {
     lpcn_model_host m;
@@ -880,6 +881,7 @@ int lpcnet_hip_model_layout(const unsigned char *data, int len, int *out)
     for (int w = 0; w < LPCN_WAVES; w++) {
         for (int k = 0; k < 4; k++) out[1 + w * 7 + k] = m.pk_a_bound[w][k];
         for (int k = 0; k < 3; k++) out[1 + w * 7 + 4 + k] = m.pk_a_allh[w][k];
+        out[57 + w] = m.pk_a_head[w];
     }
     lpcn_model_release(&m);
     return 0;

@@ -146,8 +146,10 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
         std::vector<uint8_t> b((size_t)LPCN_WAVES * nwv * 64, 0);
         for (int wv = 0; wv < LPCN_WAVES; ++wv)
             for (int j = 0; j < m->nw; ++j) {
-                memcpy(&w[((size_t)wv * nwv + j) * 64 * item_dw], &src[((size_t)wv * m->nw + j) * 64 * item_dw], 64 * item_dw * 4);
-                memcpy(&b[((size_t)wv * nwv + j) * 64], &m->pk_a_blk[((size_t)wv * m->nw + j) * 64], 64);
+                // the early head of slot 0, [nw - head, nw) in the model, stays end-aligned in the compiled variant's item array
+                const int jd = j >= m->nw - m->pk_a_head[wv] ? j + (nwv - m->nw) : j;
+                memcpy(&w[((size_t)wv * nwv + jd) * 64 * item_dw], &src[((size_t)wv * m->nw + j) * 64 * item_dw], 64 * item_dw * 4);
+                memcpy(&b[((size_t)wv * nwv + jd) * 64], &m->pk_a_blk[((size_t)wv * m->nw + j) * 64], 64);
             }
         const uint32_t *d = nullptr;
         if ((rc = upload<uint32_t>(e, &d, w.data(), w.size()))) return fail(rc);
@@ -163,6 +165,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     UP(int, a_row, m->pk_a_row, LPCN_WAVES * 3 * 64);
     UP(int, a_bound, bound, LPCN_WAVES * 4);
     UP(int, a_allh, allh, LPCN_WAVES * 3);
+    UP(int, a_head, m->pk_a_head, LPCN_WAVES);
     UP(float, emb_sig, m->pk_emb[0], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
     UP(float, emb_pred, m->pk_emb[1], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
     UP(float, emb_exc, m->pk_emb[2], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
@@ -464,8 +467,7 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.fc_base = fc_from_frames ? b->d_fc_base : nullptr;
     a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
     a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
-    a.tune = getenv("LPCNET_HIP_TUNE") ? atoi(getenv("LPCNET_HIP_TUNE")) : 0;
-    a.hmir = getenv("LPCNET_HIP_SCALAR_GRUB") ? b->d_hmir : nullptr;         // (work in progress: opt-in until the row dealing follows the shorter GRU-B)
+    a.hmir = getenv("LPCNET_HIP_NO_SCALAR_GRUB") ? nullptr : b->d_hmir;      // (tools: the LDS + DPP form of GRU-B for comparison)
     HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
     const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0;
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);

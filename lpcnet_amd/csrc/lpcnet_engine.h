@@ -39,6 +39,7 @@ extern "C" {
 #define LPCN_WG_THREADS 512
 #define LPCN_WAVES      8
 #define LPCN_MAX_SLOTS  3
+#define LPCN_EARLY_MAX  24     /* most items of a candidate slot that waves 4..7 may compute one sample ahead (float blobs) */
 
 typedef struct lpcn_model_host {
     int is_int8;                 /* blob flavour: 0 = float qweights (DISABLE_DOT_PROD), 1 = int8 (DOT_PROD)  */
@@ -70,6 +71,7 @@ typedef struct lpcn_model_host {
     int32_t *pk_a_row;    /* [8][3 slots][64]               GRU-A row (0..1151) or -1          */
     int32_t  pk_a_bound[LPCN_WAVES][LPCN_MAX_SLOTS + 1];    /* item index where each slot starts */
     int32_t  pk_a_allh[LPCN_WAVES][LPCN_MAX_SLOTS];        /* 1 if every live row of the slot is a candidate-state row */
+    int32_t  pk_a_head[LPCN_WAVES];   /* float blobs: chain items [0, head) of slot 0's rows sit at items [nw - head, nw) (computed one sample ahead) */
     float   *pk_b_w;      /* GRU-B input weights re-blocked [blk][row-in-group 8][k 4] per group */
     int32_t *pk_b_start;  /* [6 groups + 1] first block of each group in pk_b_w                */
     uint8_t *pk_b_blk;    /* [nb_b] input block index per block                                */

@@ -77,24 +77,34 @@ static int cmp_group_desc(const void *a, const void *b)
     return x->group - y->group;
 }
 
-/* ---- float blobs, dealing v2 (default; LPCN_DEAL=1 selects the round-1 dealing) ---------------------------------------
+/* ---- float blobs: dealing with split candidate chains -------------------------------------------------------------------
  * Slots are built separately from the candidate-row groups (6 slots, never mixed with update/reset rows) and from the
- * update/reset groups (12 slots).  Waves 0..3 run GRU-B, waves 4..7 may compute ONE candidate slot a sample ahead in
- * GRU-B's shadow ("early", free in the gather-dependent part of the step); a GRU-B wave may run ONE candidate slot
- * first, inside the window in which everybody waits for the leader and the gather (WIN items long).  Every placement of
- * the candidate slots (at most one per wave: 8!/2! = 20 160) is tried, the update/reset slots follow longest-first to
- * the wave that ends up cheapest, and the placement with the smallest step estimate wins:
- *   T(wave) = start(wave) + exposed items x clk per item   (constants from the in-kernel phase clocks). */
+ * update/reset groups (12 slots).  A wave takes at most one candidate slot and runs it FIRST: candidate rows start from
+ * bias + diag*h, which needs neither the new sample's indices nor the gathered embedding rows, so their items fill the
+ * window in which everybody waits for the leader and the gather (WIN items long).  Waves 4..7 do not run GRU-B: they
+ * compute the HEAD of their candidate chains (the first `head` blocks of every row) one sample ahead, in GRU-B's shadow,
+ * park the partial sums, and only the tail is left for the gather window.  (A row's sum is sequential, but nothing says
+ * it has to be formed in one go.)  With GRU-B at ~7.2 k clk and ~370 clk per item beside a GRU-B wave, a head of
+ * LPCN_DEAL_EH = 20 items measured best.  Every placement of the candidate slots (at most one per wave: 8!/2! = 20 160) is
+ * tried, the update/reset slots follow longest-first to the wave that ends up cheapest, and the placement with the
+ * smallest step estimate wins:  T(wave) = max(gather lands, candidate tail done) + update/reset items x clk per item
+ * (constants from the in-kernel phase clocks, profiles/r03_phase_clocks.txt). */
 typedef struct { int items[LPCN_WAVES], nsl[LPCN_WAVES], nzr[LPCN_WAVES], cand[LPCN_WAVES], zr_items[LPCN_WAVES]; } deal_state;
+static int g_deal_eh = 20;
+
+static int deal_head(int w, int cand)
+{
+    if (w < LPCN_WAVES / 2 || cand <= 0) return 0;
+    const int eh = g_deal_eh < LPCN_EARLY_MAX ? g_deal_eh : LPCN_EARLY_MAX;
+    return cand < eh ? cand : eh;
+}
 
 static long deal_wave_cost(const deal_state *d, int w)
 {
-    enum { WIN = 14 };
-    if (w >= LPCN_WAVES / 2)                        /* early wave: its candidate slot costs nothing here */
-        return 3600 + 400L * d->nzr[w] + 350L * d->zr_items[w];
-    int exposed = d->zr_items[w];
-    if (d->cand[w] > 0) exposed += d->cand[w] >= 10 ? (d->cand[w] > WIN ? d->cand[w] - WIN : 0) : d->cand[w];
-    return 2600 + 200L * d->nsl[w] + 250L * exposed;
+    enum { WIN = 10 };
+    const int first = d->cand[w] - deal_head(w, d->cand[w]);          /* candidate items left for the gather window */
+    const int exposed = first > WIN ? first - WIN : 0;
+    return 3800 + 330L * exposed + 330L * d->zr_items[w] + 150L * d->nsl[w];
 }
 
 /* slot_max[0..nc) candidate slots, [nc..ns) update/reset slots (both descending); returns 0 and wave_of[] or -1 */
@@ -121,8 +131,7 @@ static int deal_v2(const int *slot_max, int nc, int ns, int cap, int *wave_of)
                 int pick = -1;
                 long pick_cost = 0;
                 for (int w = 0; w < LPCN_WAVES; w++) {
-                    /* a GRU-B wave that runs a candidate slot first keeps two gather register sets in flight: one more slot only */
-                    const int maxsl = (w < LPCN_WAVES / 2 && d.cand[w] > 0) ? 2 : LPCN_MAX_SLOTS;
+                    const int maxsl = LPCN_MAX_SLOTS;
                     if (d.nsl[w] >= maxsl || d.items[w] + slot_max[z] > cap) continue;
                     deal_state t = d;
                     t.items[w] += slot_max[z]; t.nsl[w]++; t.nzr[w]++; t.zr_items[w] += slot_max[z];
@@ -179,8 +188,12 @@ static int pack_gru_a(lpcn_model_host *m)
         g[i].group = i; g[i].count = *idx++; g[i].pos = idx; g[i].first_block = blk;
         idx += g[i].count; blk += g[i].count;
     }
-    const char *deal_env = getenv("LPCN_DEAL");           /* "1" = the round-1 dealing (kept for A/B measurements) */
-    const int deal2 = !m->is_int8 && !(deal_env && deal_env[0] == '1');
+    const int deal2 = !m->is_int8;                        /* float blobs: split candidate chains (see deal_wave_cost) */
+    {
+        const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
+        g_deal_eh = (eh && *eh) ? atoi(eh) : 20;
+        if (g_deal_eh < 0) g_deal_eh = 0;
+    }
     if (deal2) {                                    /* candidate groups first (6 slots), then update/reset groups (12 slots) */
         row_group c[NG], z[NG];
         int nc = 0, nz = 0;
@@ -257,7 +270,7 @@ static int pack_gru_a(lpcn_model_host *m)
         for (int w = 0; w < LPCN_WAVES; w++) items[w] = items2[w];
         for (int s = 0; s < NSLOT; s++) wave_of[s] = newid[wave_of[s]];
     }
-    if (deal2) {                                    /* dealing v2 replaces the assignment above */
+    if (deal2) {                                    /* float blobs: the enumeration replaces the assignment above */
         int nc = 0, w2[NSLOT];
         while (nc < NSLOT && slot_allh[nc]) nc++;
         static const int caps[] = {30, 32, 36, 40, 0};
@@ -291,27 +304,27 @@ static int pack_gru_a(lpcn_model_host *m)
     if ((!m->pk_a_w && !m->pk_a_wq) || !m->pk_a_blk || !m->pk_a_row) return -1;
     for (int i = 0; i < LPCN_WAVES * LPCN_MAX_SLOTS * 64; i++) m->pk_a_row[i] = -1;
 
-    /* Slot order inside a wave.  Waves 0..3 (GRU-B waves when S = 4) take their candidate-only slot
-     * first: they start it while the new sample's gather is in flight.  Waves 4..7 take it LAST (slot
-     * index 2): they compute it one sample ahead, in the shadow of GRU-B, and then only run items
-     * [0, bound[2]) in the gather-dependent part of the sample -- no items to skip over. */
-    /* (int8 blobs: GRU-B is too short to hide a whole slot behind, every wave keeps its candidate slot first) */
-    const int early_from = LPCN_WAVES - n_early_max;
+    /* Slot order inside a wave.  Float blobs: the candidate-only slot comes first on every wave (it runs while the new
+     * sample's gather is in flight); on waves 4..7 the first `head` items of its chains are stored END-ALIGNED in the item
+     * array, [nw - head, nw): the kernel runs them one sample ahead in GRU-B's shadow and starts the slot from the parked
+     * partial sums.  int8 blobs: no early work (their GRU-B is too short to hide any), slots in dealing order. */
     int slot_at[LPCN_WAVES][LPCN_MAX_SLOTS];
     for (int w = 0; w < LPCN_WAVES; w++) {
         int list[LPCN_MAX_SLOTS], n = 0, hslot = -1;
         for (int k = 0; k < LPCN_MAX_SLOTS; k++) slot_at[w][k] = -1;
         for (int s = 0; s < NSLOT; s++) if (wave_of[s] == w) list[n++] = s;
-        if (w >= early_from)
+        if (deal2)
             for (int i = 0; i < n; i++) if (slot_allh[list[i]]) { hslot = list[i]; break; }
         int k = 0;
+        if (hslot >= 0) slot_at[w][k++] = hslot;
         for (int i = 0; i < n; i++) if (list[i] != hslot) slot_at[w][k++] = list[i];
-        if (hslot >= 0) slot_at[w][LPCN_MAX_SLOTS - 1] = hslot;
+        m->pk_a_head[w] = (hslot >= 0) ? deal_head(w, slot_max[hslot]) : 0;
     }
     for (int w = 0; w < LPCN_WAVES; w++) {
         int cur = 0;
         for (int k = 0; k < LPCN_MAX_SLOTS; k++) {
             const int s = slot_at[w][k], j0 = cur;
+            const int head = (k == 0) ? m->pk_a_head[w] : 0;       /* chain items [0, head) of slot 0 live at [nw - head, nw) */
             m->pk_a_bound[w][k] = j0;
             m->pk_a_allh[w][k] = 1;
             if (s < 0) continue;
@@ -323,7 +336,8 @@ static int pack_gru_a(lpcn_model_host *m)
                     int lane = 8 * q + r;
                     m->pk_a_row[(w * LPCN_MAX_SLOTS + k) * 64 + lane] = rg->group * 8 + r;
                     for (int j = 0; j < rg->count; j++) {
-                        size_t item = ((size_t)w * nw + (j0 + j)) * 64 + lane;
+                        const int pos = j < head ? nw - head + j : j0 + (j - head);
+                        size_t item = ((size_t)w * nw + pos) * 64 + lane;
                         if (m->is_int8) {      /* int8 block = [out 8][in 4] (dump_lpcnet.py:106): the row's 4 bytes are one dword */
                             const signed char *blkq = (const signed char *)m->a_w + (size_t)(rg->first_block + j) * 32;
                             memcpy(&m->pk_a_wq[item], blkq + r * 4, 4);
@@ -336,7 +350,7 @@ static int pack_gru_a(lpcn_model_host *m)
                 }
             }
             m->pk_a_allh[w][k] = allh;
-            cur += slot_max[s];
+            cur += slot_max[s] - head;
         }
         m->pk_a_bound[w][LPCN_MAX_SLOTS] = cur;
     }
@@ -556,7 +570,10 @@ int lpcn_model_selftest(const lpcn_model_host *m)
                 if (row >= LPCN_ROWS_A || seen[row]) { rc = 2; goto done; }
                 seen[row] = 1;
                 if (m->pk_a_allh[wv][k] && row < 2 * LPCN_N_A) { rc = 3; goto done; }
-                for (int j = j0; j < j1; j++) {
+                const int head = k == 0 ? m->pk_a_head[wv] : 0;       /* slot 0's early items sit end-aligned */
+                if ((wv < LPCN_WAVES / 2 && m->pk_a_head[wv]) || head < 0 || head > LPCN_EARLY_MAX || m->pk_a_bound[wv][LPCN_MAX_SLOTS] + m->pk_a_head[wv] > m->nw) { rc = 7; goto done; }
+                for (int jj = j0 - head; jj < j1; jj++) {
+                    const int j = jj < j0 ? m->nw + (jj - j0) : jj;
                     size_t item = ((size_t)wv * m->nw + j) * 64 + lane;
                     int p = m->pk_a_blk[item];
                     for (int c = 0; c < 4; c++) {

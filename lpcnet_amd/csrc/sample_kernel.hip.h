@@ -49,6 +49,7 @@ struct LpcnSampleArgs {
     const int *a_row;                               // [8][3][64]
     const int *a_bound;                             // [8][4]
     const int *a_allh;                              // [8][3]
+    const int *a_head;                              // [8] float blobs: items [NW - head, NW) = the first `head` chain items of slot 0's rows, computed one sample ahead
     const float *a_bias1;                           // [1152] recurrent bias row
     const float *a_diag;                            // [1152]
     const float *b_w;                               // [nb_b][8][4] fp32, or [nb_b/4][8][4 blocks] dwords of 4 int8
@@ -70,8 +71,7 @@ struct LpcnSampleArgs {
     short *pcm;                                     // [stream] x pcm_stride samples, frame f at +f*160
     long long pcm_stride;
     lpcn_stream_state *state;                       // [stream]
-    int tune;                                       // experiment switches (tools; LPCNET_HIP_TUNE), 0 = product behaviour
-    float *hmir;                                    // [workgroup][S][384] L2-resident mirror of the GRU-A state for GRU-B's scalar loads (or NULL)
+    float *hmir;                                    // [n_streams + 4][384] L2-resident mirror of the GRU-A state for GRU-B's scalar loads (or NULL)
     float *dbg;                                     // optional per-sample trace (tests)
     unsigned long long *prof;                       // optional: [8] shader-clock totals per phase, workgroup 0 wave 0
 };
@@ -361,9 +361,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row[1] >= 0) != 0ull ? 2 : 0) |
                                                         (__ballot(row[2] >= 0) != 0ull ? 4 : 0));
     const bool has2 = (has_slot & 4) != 0;
-    // waves that do not run GRU-B and whose LAST slot holds only candidate rows compute that slot one sample ahead
-    const bool early_wave = __builtin_amdgcn_readfirstlane(((tid0 >> 6) >= S && as_global(Ap->a_allh)[(tid0 >> 6) * 3 + 2] != 0 &&
-                                                            __ballot(row[2] >= 0) != 0ull && b3 > b2) ? 1 : 0) != 0;      // wave-uniform
+    // Float blobs: waves that do not run GRU-B compute the HEAD of their candidate slot's chains (the first `hl` blocks of every
+    // row of slot 0, stored end-aligned at items [NW - hl, NW) by model_pack.c) one sample ahead, in GRU-B's shadow, and park
+    // the partial sums in the rows' sm_pre cells; the slot then starts from those in the next sample.
+    const int hl = I8 ? 0 : __builtin_amdgcn_readfirstlane(as_global(Ap->a_head)[tid0 >> 6]);
+    const bool early_wave = !I8 && hl > 0;                  // wave-uniform (model_pack.c deals heads to waves 4..7 only: never a GRU-B wave)
 
     // ------------------------------------------------------------------ LDS residents -------
     {
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // slot for the NEXT sample while GRU-B runs: those rows start from bias + diag*h, which is final
     // once the gate stage is done, and they make up most of GRU-A's blocks.  (model_pack.c puts the
     // candidate-only slot of waves 4..7 last, so the rest of the sample simply ends at item bound[2].)
-    bool early_done = false;                                 // wave-uniform
+    bool head_ready = false;                                 // wave-uniform: the parked partial sums belong to the sample about to start
     const uint32_t flag_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::flag);
     auto publish_indices = [&]() {                           // after the sm_idx writes of the same lane
         asm volatile("ds_write_b32 %0, %1" :: "v"(flag_addr), "v"(seq) : "memory");
@@ -616,7 +618,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_PROF(5);
             float acc[S] = {};                               // (initialised for the same reason as ge)
             // state blocks are fetched PF items ahead of their use
-            constexpr int PF = 2;
+#ifndef LPCN_PF
+#define LPCN_PF 2
+#endif
+            constexpr int PF = LPCN_PF;
             HT hq[PF + 1] = {};
             auto fetch_h = [&](const int j) {
                 uint32_t pk = offp[j >> 1];
@@ -672,6 +677,24 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     acc[0] = av[0]; acc[1] = av[1];
                     if constexpr (S == 4) { acc[2] = av[2]; acc[3] = av[3]; }
                 }
+#ifndef LPCN_PARITY_MFMA
+#define LPCN_PARITY_MFMA 0
+#endif
+                if constexpr (!FAST && S >= 2 && LPCN_PARITY_MFMA) {
+                    // PARITY: the same instruction as a MULTIPLIER -- with C = -0.0 the fused result is the separately rounded
+                    // product bit for bit (x + (-0) = x, also for zeros), one instruction instead of the four DPP multiplies of a
+                    // column; the sums stay ordinary adds in the reference's order.
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    f4 nz;
+                    nz[0] = nz[1] = nz[2] = nz[3] = -0.f;
+                    asm volatile("" : "+v"(nz));             // (one 4-register tuple, re-materialised per item)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f4 pv = __builtin_amdgcn_mfma_f32_4x4x1f32(hk[c], wk[c], nz, 0, 0, 0);
+                        acc[0] = acc[0] + pv[0]; acc[1] = acc[1] + pv[1];
+                        if constexpr (S == 4) { acc[2] = acc[2] + pv[2]; acc[3] = acc[3] + pv[3]; }
+                    }
+                } else
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if constexpr (FAST) {
@@ -703,9 +726,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 r = r < 0 ? 0 : r;
                 const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
                 const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
+                const bool parked = k == 0 && early_wave;      // slot 0 continues from the partial sums of its early head
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    pre_b[slot][s] = bias + diag * sm_hT[n * S + s];
+                    pre_b[slot][s] = parked ? sm_pre[r * S + s] : bias + diag * sm_hT[n * S + s];
                     pre_c[slot][s] = sm_cond[r * S + s];
                 }
             };
@@ -758,11 +782,37 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             constexpr int JG = 8, JSTAR_MAX = 18, JSTAR_MIN = I8 ? 18 : 10;   // (JG: the leader publishes ~2 k clk after the tree barrier = ~8 items)
             int jstar = b1 >= 18 ? 18 : (b1 >= 14 ? 14 : 10);
             LPCN_REMAT_S(jstar);
-            // skip2: this wave already finished its last slot for this sample while GRU-B of the previous
-            // sample was running (see P3): its items end at b2 and slot 2 is neither parked nor stored again
-            const bool skip2 = early_done;
-            early_done = false;
-            const int jend = skip2 ? b2 : b3;
+            // The early head of slot 0 (see `hl`): one compile-time chain over the last LPCN_EARLY_MAX items, entered at NW - hl.
+            auto run_head = [&]() __attribute__((always_inline)) {
+                {
+                    int r = row[0];
+                    LPCN_REMAT_V(r);
+                    r = r < 0 ? 0 : r;
+                    const int n = r - 2 * NA;
+                    const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) acc[s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
+                }
+                int e0 = NW - hl;
+                LPCN_REMAT_S(e0);
+                // (every step issues the same LDS read whether its item runs or not: otherwise the compiler's s_waitcnt
+                // bookkeeping degrades to full waits and the state prefetch no longer overlaps anything)
+                constexpr int J0 = NW - LPCN_EARLY_MAX < 0 ? 0 : NW - LPCN_EARLY_MAX;
+#pragma unroll
+                for (int j = 0; j < PF; ++j) if (J0 + j < NW) fetch_h(J0 + j);
+                auto step = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (j < NW) {
+                        if constexpr (j + PF < NW) fetch_h(j + PF);
+                        if (j >= e0) mac(j);
+                        self(self, std::integral_constant<int, j + 1>{});
+                    }
+                };
+                step(step, std::integral_constant<int, J0>{});
+                row_store(0);                                // park the partial sums
+            };
+            if (early_wave && !head_ready) { run_head(); head_ready = true; }     // first sample of the launch only
+            const int jend = b3;
             const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR_MIN) ? 1 : 0);
             if (jmode == 0) {
                 row_pre(0, 0); row_pre(1, 1); row_pre(2, 2);
@@ -772,7 +822,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 gather(2, 1);
                 gather(0, 2);
                 row_init(1, 0, false);
-                row_init(2, 1, false, !skip2);               // (candidate rows still need their input part)
+                row_init(2, 1, false);
                 row_init(0, 2, true);
             } else {
                 int r = row[0];
@@ -781,7 +831,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    acc[s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
+                    acc[s] = early_wave ? sm_pre[r * S + s] : acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
                 }
             }
             // issue priority for the part of GRU-A that everybody waits for: int8 -- the younger wave of each SIMD pair sees
@@ -799,7 +849,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 if ((j == 10 || j == 14 || j == 18) && j >= JSTAR_MIN && j <= JSTAR_MAX && __builtin_expect(j == jstar, 0)) {
                     if (jmode) {
                         row_init(1, 0, false);
-                        if (has2) { row_init(2, 1, false, !skip2); gather(0, 0); }     // (two-slot waves already hold slot 0's rows in set 1)
+                        if (has2) { row_init(2, 1, false); gather(0, 0); }     // (two-slot waves already hold slot 0's rows in set 1)
                         __builtin_amdgcn_s_waitcnt(0xC07F);
                     }
                 }
@@ -838,10 +888,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (b1 >= jend) {
                 row_swap(0, 1);
                 row_swap(1, 2);
-                if (!skip2) row_store(2);
+                row_store(2);
             } else if (b2 >= jend) {
                 row_swap(1, 2);
-                if (!skip2) row_store(2);
+                row_store(2);
             } else {
                 row_store(2);
             }
@@ -919,7 +969,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                 }
             }
-            if (Ap->tune & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                                   // B2
             LPCN_PROF(1);
 
@@ -975,8 +1024,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             int gb_qa = 24;
             if constexpr (FAST && !I8) {
                 const int hw = wave < LPCN_WAVES / 2 ? wave + LPCN_WAVES / 2 : wave;       // the helper wave of this pair
-                const auto *bd = as_global(Ap->a_bound) + hw * 4;
-                const int e = (hw >= S && as_global(Ap->a_allh)[hw * 3 + 2] != 0) ? bd[3] - bd[2] : 0;
+                const int e = hw >= S ? as_global(Ap->a_head)[hw] : 0;       // items of the helper's early head
                 gb_qa = __builtin_amdgcn_readfirstlane((24 + (9 * e) / 32) / 2);
                 gb_qa = gb_qa > 24 ? 24 : gb_qa;
             }
@@ -1007,15 +1055,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             };
             const bool gate_wave = gb_split ? (wave % GB_W == 0) : (wave < S);      // wave-uniform
             if constexpr (!I8 && !FAST) {
-                if (gb_scalar) { ++gbseq; if (!gate_wave && !(Ap->tune & 32)) mirror_arrive(); }
+                if (gb_scalar) { ++gbseq; if (!gate_wave) mirror_arrive(); }
             }
             float zrh = 0.f, rec = 0.f;
             const int s = gb_split ? wave / GB_W : wave;     // (stream of a gate wave)
             const int r = lane < RB ? lane : RB - 1;
             if (gate_wave) {
                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
-                if ((Ap->tune & 3) == 0) __builtin_amdgcn_s_setprio(3);
-                else if ((Ap->tune & 3) == 1) __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(3);                 // (priority 1 or none: the same step time, measured)
                 const int g = r >> 3, ri = r & 7;
                 zrh = sm_bbias[r] + sm_condb[s * RB + r];                     // src/nnet.c:351
                 rec = sm_bbias[RB + r];
@@ -1147,13 +1194,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     for (int j = 0; j < NB; ++j) rec = __builtin_fmaf(sm_brec[j * RB + r], sm_hB[s * NB + j], rec);
                     zrh = zrh + gb_part_fast(s, 0, gb_qa);
                     (void)g; (void)ri;
-                } else if (gb_scalar && !(Ap->tune & 16)) {
+                } else if (gb_scalar) {
                     // state through SGPRs: the whole 96-block loop is one hand-scheduled assembly block (tools/gen_grub_asm.py)
+                    // (a ring of 8 sample slots with one s_dcache_inv per turn instead of one per sample was measured: 102.7 vs 104.9 M --
+                    // the larger footprint costs more in the 16 KB scalar cache than the invalidations do)
                     const float *hb = Ap->hmir + ((size_t)blockIdx.x * S + s) * NA;
 #pragma unroll
                     for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
-                    if (!(Ap->tune & 32)) mirror_arrive();
-                    if (!(Ap->tune & 8)) mirror_wait();
+                    mirror_arrive();
+                    mirror_wait();
                     uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::bw + (sm_bstart[g] * 8 + ri) * 16);   // this lane's row, block 0 of its group
                     asm volatile(
 #include "grub_scalar_loop.inc"
@@ -1214,33 +1263,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 LPCN_PROF(8);      // GRU-B input mat-vec
                 __builtin_amdgcn_s_setprio(0);
             } else if (early_wave) {
-                // ---- GRU-A's last slot of the next sample (runs in the shadow of GRU-B): items [b2, b3)
-                {
-                    int r = row[2];
-                    LPCN_REMAT_V(r);
-                    r = r < 0 ? 0 : r;
-                    const int n = r - 2 * NA;
-                    const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        acc[s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < PF && j < NW; ++j) fetch_h(j);
-                auto run_early = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
-                    constexpr int j = decltype(jc)::value;
-                    if constexpr (j < NW) {
-                        if (__builtin_expect(j >= b3, 0)) return;
-                        if (j + PF < NW) fetch_h(j + PF);
-                        if (j >= b2) mac(j);
-                        self(self, std::integral_constant<int, j + 1>{});
-                    }
-                };
-                run_early(run_early, std::integral_constant<int, 0>{});
-                row_store(2);
-                early_done = true;
-            
+                // ---- the head of the next sample's candidate chains (runs in the shadow of GRU-B)
+                run_head();
             }
             if constexpr (FAST && !I8) {
                 if (gb_fsplit) {                             // (workgroup-uniform)
