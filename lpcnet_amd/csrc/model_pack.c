@@ -99,12 +99,24 @@ static int deal_head(int w, int cand)
     return cand < eh ? cand : eh;
 }
 
+/* Finishing time of a wave's part of GRU-A in the sample step, clk after the tree barrier (fitted to profiles/r03_phase_clocks.txt):
+ *  - its update/reset items cannot start before the leader has published the indices and the gathered rows have landed and
+ *    been folded into the start values: TG;
+ *  - a candidate tail of at least 10 items (the kernel's run-ahead mode) starts at T0 and keeps the wave busy at CI clk per
+ *    item (both waves of a SIMD running items) -- a shorter tail waits for the gather like everything else. */
+static int g_deal_tg = 5000, g_deal_t0a = 1600, g_deal_t0b = 900, g_deal_ci = 395, g_deal_cu = 320;
 static long deal_wave_cost(const deal_state *d, int w)
 {
-    enum { WIN = 10 };
-    const int first = d->cand[w] - deal_head(w, d->cand[w]);          /* candidate items left for the gather window */
-    const int exposed = first > WIN ? first - WIN : 0;
-    return 3800 + 330L * exposed + 330L * d->zr_items[w] + 150L * d->nsl[w];
+    const int tail = d->cand[w] - deal_head(w, d->cand[w]);           /* candidate items left for the sample step itself */
+    const long after_gather = g_deal_tg + (long)g_deal_cu * d->zr_items[w];
+    long t;
+    if (tail >= 10) {
+        t = (w < LPCN_WAVES / 2 ? g_deal_t0a : g_deal_t0b) + (long)g_deal_ci * (tail + d->zr_items[w]);
+        if (t < after_gather) t = after_gather;
+    } else {
+        t = after_gather + (long)g_deal_cu * tail;
+    }
+    return t + 100L * d->nsl[w];
 }
 
 /* slot_max[0..nc) candidate slots, [nc..ns) update/reset slots (both descending); returns 0 and wave_of[] or -1 */
@@ -193,6 +205,8 @@ static int pack_gru_a(lpcn_model_host *m)
         const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
         g_deal_eh = (eh && *eh) ? atoi(eh) : 20;
         if (g_deal_eh < 0) g_deal_eh = 0;
+        const char *cm = getenv("LPCN_DEAL_COST");        /* tools: "TG,T0a,T0b,CI,CU" of deal_wave_cost */
+        if (cm && *cm) sscanf(cm, "%d,%d,%d,%d,%d", &g_deal_tg, &g_deal_t0a, &g_deal_t0b, &g_deal_ci, &g_deal_cu);
     }
     if (deal2) {                                    /* candidate groups first (6 slots), then update/reset groups (12 slots) */
         row_group c[NG], z[NG];
