@@ -13,7 +13,8 @@ value    = whole-job 16 kHz samples per second (sum over GPUs / max-over-ranks t
            Every stream of every rank has its own seeded feature file (1000 + rank*streams + s); after the timed loop
            `--check-streams` streams of the timed output are replayed on the plain-C oracle (checker leg) and
            compared bit for bit: `parity_checked` in the JSON line.
-           `--gpus N` without a launcher re-executes itself under `python -m torch.distributed.run` with N ranks.
+           `--gpus N` without a launcher re-executes itself under `python -m torch.distributed.run` with N ranks;
+           `--gpus 2 --share-device` rehearses that path on ONE GPU (both ranks on device 0, gloo control plane).
 roofline = the sample kernel (dominant, >98 % of the step).  SURVEY.md §8(d): not MFMA; the primary bound
            is on-chip operand bandwidth, so `achieved` = algorithmic operand bytes per stream-sample
            (286 704 B fp32 / 96 432 B int8: every weight and table entry once per sample) x samples per
@@ -55,22 +56,33 @@ MEASURED_FP32_MUL_ADD_TFLOPS = 58.9      # tools/ubench/peaks.hip on this box (p
 
 
 def _cpu_worker(args):
-    kind, frames, seed, flavour = args
+    """One single-threaded reference process pinned to its own core: untimed warm-up, then best of `reps` timed passes."""
+    kind, frames, seed, flavour, cpu, reps = args
+    if cpu is not None:
+        try:
+            os.sched_setaffinity(0, {cpu})
+        except Exception:
+            pass
     from lpcnet_amd import synth
-    blob = synth.blob_bytes(synth.make_model(flavour="int8" if flavour == "ai" else "float"))
+    blob = synth.blob_bytes(synth.make_model(flavour="int8" if flavour in ("ai", "ni") else "float"))
     f = synth.make_features(seed, frames)
     if kind == "reference":
         from oracle import ref
         lib = ref.RefLib(flavour)
-        st = lib.new_state(blob)
+        new_state = lambda: lib.new_state(blob)
+    else:
+        from oracle import orc
+        om = orc.OracleModel(blob)
+        new_state = om.new_state
+    new_state().synthesize(f[:min(frames, 100)])             # warm-up: page in the model, the tables, the code
+    best = None
+    for _ in range(reps):
+        st = new_state()
         t0 = time.perf_counter()
         st.synthesize(f)
-        return time.perf_counter() - t0
-    from oracle import orc
-    st = orc.OracleModel(blob).new_state()
-    t0 = time.perf_counter()
-    st.synthesize(f)
-    return time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
 
 
 def usable_cores():
@@ -95,33 +107,90 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _flavour_runs(flavour):
+    """Can this box execute the flavour at all?  (the -march=native builds carry the BUILD host's instruction set)"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "print(bench._cpu_worker(('reference', 4, 1000, %r, None, 1)))" % (ROOT, flavour))
+    try:
+        return subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120).returncode == 0
+    except Exception:
+        return False
+
+
 def cpu_baseline(int8_line=False):
-    """Reference CPU path on this box's host cores: nproc independent single-threaded processes
-    (the library has no threading), ~10-20 s of CPU work in total; A-f (AVX2 float) and A-i (AVX2 int8, the
-    reference's default x86 build, src/vec_avx.h:39-41)."""
+    """Reference CPU path on this box's host cores.  The library is single-threaded, so the aggregate is `procs` independent
+    processes, each PINNED to its own core (an unpinned pool under a CPU quota gave a 1.7x run-to-run spread), one untimed
+    warm-up pass and the best of three timed passes per process.  Reported per flavour: the sum of the per-process rates, the
+    median rate x procs and their ratio (`unstable` when they differ by more than 20 %), and one process alone on one core.
+    Flavours: A-f / A-i = -O3 -mavx2 -mfma float / int8 (the reference's default x86 build, src/vec_avx.h:39-41);
+    N-f / N-i = -Ofast -march=native as README.md:55-57 recommends (native to the host they were BUILT on; skipped when this
+    box cannot execute them)."""
     from oracle import ref
     have = ref.available("af") and ref.available("ai")
     kind = "reference" if have else "port"
     cores = usable_cores()
-    procs = max(1, min(cores, 32))
-    names = {"af": "reference AVX2+FMA float build (oracle/_ref af, -DDISABLE_DOT_PROD)",
-             "ai": "reference AVX2 int8 build (oracle/_ref ai, the reference's default on x86)", "port": "plain-C oracle"}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    procs = max(1, min(cores, 32, len(allowed)))
+    if procs > 2 and procs == cores:
+        procs -= 1                                           # leave the quota's last core to this (parent) process
+    pins = [allowed[(i * len(allowed)) // procs] for i in range(procs)]       # spread over the mask (distinct physical cores where possible)
+    names = {"af": "reference AVX2+FMA float build (oracle/_ref af: -O3 -mavx2 -mfma -DDISABLE_DOT_PROD)",
+             "ai": "reference AVX2 int8 build (oracle/_ref ai: -O3 -mavx2 -mfma, the reference's default on x86)",
+             "nf": "reference float build with -Ofast -march=native (oracle/_ref nf, README.md:55-57; native to the build host)",
+             "ni": "reference int8 build with -Ofast -march=native (oracle/_ref ni, README.md:55-57; native to the build host)",
+             "port": "plain-C oracle"}
+    todo = [fl for fl in ("af", "ai", "nf", "ni") if ref.available(fl)] if have else ["port"]
     flav = {}
-    for fl in (("af", "ai") if have else ("port",)):
-        frames = 1000 if have else 250                       # ~1.3 s (A-f) / ~0.7 s (A-i) / ~1.5 s (plain C) per process
+    for fl in todo:
+        if fl in ("nf", "ni") and not _flavour_runs(fl):
+            flav[fl] = {"value": None, "build": names[fl], "note": "not executable on this host (built with -march=native elsewhere)"}
+            continue
+        frames = 1000 if have else 250                       # ~1.3 s (A-f) / ~0.7 s (A-i) / ~1.5 s (plain C) per pass
         t0 = time.perf_counter()
         with mp.get_context("spawn").Pool(procs) as pool:
-            times = pool.map(_cpu_worker, [(kind, frames, 1000 + i, fl) for i in range(procs)])
+            times = pool.map(_cpu_worker, [(kind, frames, 1000 + i, fl, pins[i], 3) for i in range(procs)])
         wall = time.perf_counter() - t0
-        flav[fl] = {"value": sum((frames - 2) * 160 / tt for tt in times),       # concurrent single-threaded processes, one per usable core
-                    "per_core": (frames - 2) * 160 / float(np.median(times)), "frames_per_process": frames, "pool_wall_s": round(wall, 1),
-                    "build": names[fl]}
+        with mp.get_context("spawn").Pool(1) as pool:        # one process alone on one pinned core
+            single = pool.map(_cpu_worker, [(kind, frames, 1000, fl, pins[0], 3)])[0]
+        n_s = (frames - 2) * 160
+        rates = [n_s / tt for tt in times]
+        total, med = float(sum(rates)), float(np.median(rates)) * procs
+        flav[fl] = {"value": total, "median_x_procs": med, "sum_over_median_x_procs": total / med, "unstable": bool(abs(total / med - 1.0) > 0.2),
+                    "per_core": float(np.median(rates)), "per_core_min": float(min(rates)), "per_core_max": float(max(rates)),
+                    "single_process_pinned": n_s / single, "realtime_factor_single": n_s / single / 16000.0,
+                    "frames_per_process": frames, "passes": "1 warm-up + best of 3", "pool_wall_s": round(wall, 1), "build": names[fl]}
     main = ("ai" if int8_line else "af") if have else "port"
     frames = flav[main]["frames_per_process"]
     return {"value": flav[main]["value"], "unit": "samples/s", "cores": procs, "kind": kind, "per_core": flav[main]["per_core"],
-            "flavour": main, "flavours": flav,
-            "sample": f"{procs} independent processes x {frames} frames ({frames / 100:.1f} s of audio each), {names[main]}; "
-                      f"{cores} usable host cores of {os.cpu_count()}"}
+            "unstable": flav[main]["unstable"], "cpu_model": cpu_model(), "flavour": main, "flavours": flav,
+            "sample": f"{procs} independent single-threaded processes, each pinned to its own core, x {frames} frames ({frames / 100:.1f} s of audio), "
+                      f"warm-up + best of 3, {names[main]}; {cores} usable host cores of {os.cpu_count()} ({cpu_model()})"}
+
+
+def kernel_source_hash():
+    """sha1 over the device sources: ties a PMC traffic file under profiles/ to the kernel it was measured with"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "lpcnet_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".inc", ".c")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _self_launch(a):
@@ -130,7 +199,7 @@ def _self_launch(a):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < a.gpus:
+    if have < a.gpus and not a.share_device:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but only {have} HIP device(s) are visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -156,6 +225,9 @@ def main():
     ap.add_argument("--int8", action="store_true",
                     help="BASELINE.json config 4: int8 (DOT_PROD) GRU-A/GRU-B weights, bit-exact vs the reference's generic int8 build "
                          "(default: float32 weights, the configuration the metric is quoted on)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal of the multi-rank path on ONE GPU: every rank uses device 0 and the control plane is gloo "
+                         "(RCCL cannot put two ranks on one device); the line it prints is a plumbing check, not a scaling number")
     a = ap.parse_args()
 
     import torch
@@ -170,9 +242,11 @@ def main():
     if a.gpus != world:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE {world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus})")
+    if a.share_device:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # RCCL: control plane only
+        dist.init_process_group("gloo" if a.share_device else "nccl", rank=rank, world_size=world)      # RCCL: control plane only
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the LPCNet HIP engine has no CPU fallback")
     torch.cuda.set_device(local)
@@ -213,7 +287,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timed_pcm = d_pcm.clone()                                # output of the last timed step (checked below)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if a.share_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -252,12 +326,19 @@ def main():
         op_bytes = LDS_OPERAND_BYTES_PER_SAMPLE_I8 if a.int8 else LDS_OPERAND_BYTES_PER_SAMPLE
         op_gbs = kernel_rate * op_bytes / 1e9
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):                           # PMC passes of this command, newest round first
-            tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_int8.json" if a.int8 else f"{rnd}_hbm_traffic.json")
+        khash = kernel_source_hash()
+        for rnd in ("r03", "r02", "r01"):                    # PMC passes of this command, newest round first
+            tag = ("_int8" if a.int8 else "") + ("_fast" if a.fast else "")
+            tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic{tag}.json")
             if os.path.exists(tpath) and (n, F) == (STREAMS_PER_GPU, FRAMES_PER_STEP):
                 try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                    traffic_src = os.path.relpath(tpath, ROOT)
+                    rec = json.load(open(tpath))
+                    # only a measurement of THIS kernel counts: the file records the hash of the kernel sources it was taken with
+                    if rec.get("kernel_source_hash") == khash:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_src = os.path.relpath(tpath, ROOT)
+                    else:
+                        traffic_src = f"stale: {os.path.relpath(tpath, ROOT)} was measured with other kernel sources"
                     break
                 except Exception:
                     traffic = None
@@ -283,7 +364,10 @@ def main():
                          "launch_ms": ms_sample, "frame_kernels_ms": ms_frame,
                          "operand_bytes_per_sample": op_bytes,
                          "note": "algorithmic operand bytes (each weight/table entry once per stream-sample); the engine keeps "
-                                 "GRU-A weights in VGPRs and shares every LDS read among the workgroup's streams, so realised LDS bytes are lower",
+                                 "GRU-A weights in VGPRs and shares every LDS read among the workgroup's streams, so realised LDS bytes are lower; "
+                                 "`traffic` comes from the rocprofv3 PMC passes recorded under profiles/ (it cannot be collected from inside the "
+                                 "process) and is null unless that file was measured with these very kernel sources",
+                         "kernel_source_hash": khash,
                          "valu_fp32": {"achieved_TFLOPs": achieved_tflops, "peak_TFLOPs": PEAK_FP32_TFLOPS,
                                        "frac": achieved_tflops / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE,
                                        "measured_mul_add_no_fma_TFLOPs": MEASURED_FP32_MUL_ADD_TFLOPS,
@@ -294,7 +378,9 @@ def main():
                                                               "frac": traffic / (ms_sample * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                                               "note": "measured PMC traffic per launch / live launch time: HBM is not a bound of this kernel"}},
         }
-        if not a.no_cpu_baseline and world == 1:             # (reported at N = 1 only: the other ranks would wait for it)
+        if a.share_device:
+            out["rehearsal"] = "all ranks on device 0, gloo control plane: a plumbing check of the multi-rank path, not a scaling number"
+        if not a.no_cpu_baseline:                            # (N > 1: rank 0 only, behind the timed region; the other ranks wait at the final barrier)
             try:
                 out["cpu_baseline"] = cpu_baseline(a.int8)
             except Exception as e:  # the baseline must never take the GPU number down with it

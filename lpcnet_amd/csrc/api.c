@@ -44,6 +44,20 @@ struct LPCNetState {
 
 _Static_assert(sizeof(struct LPCNetState) == LPCNET_HIP_STATE_BYTES, "include/lpcnet.h: LPCNET_HIP_STATE_BYTES is stale");
 
+/* include/lpcnet_hip_state.h publishes this layout with the reference's member names (the unmodified src/lpcnet_plc.c is
+ * compiled against it, integration/lpcnet_private_hip.h): every member the PLC touches must sit where that header says */
+#define LPCNetState LPCNetState_published
+#include "../../include/lpcnet_hip_state.h"
+#undef LPCNetState
+#define SAME_OFF(pub, mine) _Static_assert(offsetof(struct LPCNetState_published, pub) == offsetof(struct LPCNetState, mine), "include/lpcnet_hip_state.h is stale: " #pub)
+_Static_assert(sizeof(struct LPCNetState_published) == sizeof(struct LPCNetState), "include/lpcnet_hip_state.h is stale");
+SAME_OFF(nnet.gru_a_state, s.gru_a); SAME_OFF(nnet.gru_b_state, s.gru_b); SAME_OFF(nnet.feature_conv1_state, s.conv1_mem);
+SAME_OFF(nnet.feature_conv2_state, s.conv2_mem); SAME_OFF(old_lpc, s.old_lpc); SAME_OFF(last_sig, s.last_sig);
+SAME_OFF(deemph_mem, s.deemph_mem); SAME_OFF(last_exc, s.last_exc); SAME_OFF(frame_count, s.frame_count); SAME_OFF(hip_rng, s.rng);
+SAME_OFF(lpc, s.lpc); SAME_OFF(gru_a_condition, gru_a_condition); SAME_OFF(gru_b_condition, gru_b_condition);
+SAME_OFF(feature_buffer, feature_buffer); SAME_OFF(feature_buffer_fill, feature_buffer_fill);
+#undef SAME_OFF
+
 struct LPCNetDecState {
     LPCNetState lpcnet_state;         /* reference: src/lpcnet_private.h:50-53 */
     float vq_mem[LPCN_NB_BANDS];

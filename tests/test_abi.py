@@ -128,3 +128,29 @@ def test_bench_refuses_a_rank_count_it_cannot_get():
     env["WORLD_SIZE"] = "2"; env["RANK"] = "0"; env["LOCAL_RANK"] = "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2 --share-device`: the launcher, the rank environment, the barrier + max-over-ranks timing, the
+    per-rank feature seeds and the rank-0 JSON line of the multi-rank branch, executed on the one GPU the box has (both
+    ranks on device 0, gloo control plane).  The first real SCALE run must not be the first execution of this code."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    common = ["--steps", "2", "--warmup", "1", "--streams", "256", "--frames", "10", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device"] + common,
+                        capture_output=True, text=True, env=env, timeout=900)
+    assert r2.returncode == 0, (r2.stdout[-1000:], r2.stderr[-2000:])
+    lines = [ln for ln in r2.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    two = json.loads(lines[0])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["parity_checked"] == 8 and "rehearsal" in two
+    assert two["config"]["sharding"].startswith("2 x 256")
+    # two ranks share one GPU: the aggregate is the one-GPU figure again (256 streams leave most CUs idle, so two such
+    # batches overlap almost perfectly: between 0.9x and 2.2x)
+    assert 0.9 * one["value"] < two["value"] < 2.2 * one["value"], (one["value"], two["value"])

@@ -39,6 +39,39 @@ def test_reference_demo_links_against_the_engine(hip_lib):
     assert r.returncode == 2 and "not part of the LPCNet HIP engine" in r.stderr
 
 
+def test_unmodified_reference_plc_compiles_and_links_against_the_engine(hip_lib):
+    """SURVEY.md section 8f N3 / VERDICT r2: src/lpcnet_plc.c, the one reference file that looks INSIDE LPCNetState
+    (src/lpcnet_plc.c:176-180) and embeds it by value, builds untouched against the engine's state layout
+    (include/lpcnet_hip_state.h through the forced include integration/lpcnet_private_hip.h) and links with
+    -Wl,--no-undefined: every LPCNet symbol it needs resolves to liblpcnet_hip.so."""
+    if not os.path.exists("/root/reference/src/lpcnet_plc.c"):
+        pytest.skip("reference tree not mounted")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "gen", "plc_data.h")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "integration"), "plc"])
+    lib = os.path.join(ROOT, "oracle", "_ref", "liblpcnet_plc_hip.so")
+    needed = subprocess.run(["ldd", lib], capture_output=True, text=True).stdout
+    assert "liblpcnet_hip.so" in needed
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    for sym in ("lpcnet_init", "lpcnet_load_model", "lpcnet_reset", "lpcnet_reset_signal", "lpcnet_synthesize_impl",
+                "lpcnet_synthesize_tail_impl", "run_frame_network_deferred", "run_frame_network_flush"):
+        assert (" U " + sym) in und, sym                   # taken from the engine, not from a CPU copy of src/lpcnet.c
+    dfn = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    assert " T lpcnet_plc_update" in dfn and " T lpcnet_plc_conceal" in dfn
+    # the PLC state embeds the ENGINE's state: its size follows the engine's lpcnet_get_size()
+    import ctypes
+    from lpcnet_amd import api
+    plc = ctypes.CDLL(lib)
+    eng = api.load_library()
+    ref_state = 0
+    gf = os.path.join(ROOT, "oracle", "_ref", "liblpcnet_ref_gf.so")
+    if os.path.exists(gf):
+        r = ctypes.CDLL(gf)
+        ref_state = r.lpcnet_plc_get_size() - r.lpcnet_get_size()          # everything but the embedded LPCNetState
+        assert abs(plc.lpcnet_plc_get_size() - eng.lpcnet_get_size() - ref_state) <= 8      # (alignment padding)
+    assert plc.lpcnet_plc_get_size() > eng.lpcnet_get_size() == 8724
+
+
 def _run_demo(tmp_path, flavour, args, extra_files=()):
     d = str(tmp_path)
     with open(os.path.join(d, "weights_blob.bin"), "wb") as f:

@@ -84,6 +84,19 @@ def test_1024_distinct_streams_full_occupancy(blob_f32, hip_lib):
     b.close()
 
 
+def test_2048_distinct_float_streams_two_rounds_of_workgroups(blob_f32, hip_lib):
+    """more workgroups than CUs for the float kernel: 2048 distinct streams at S = 4 = 512 workgroups on 256 CUs,
+    a second round of workgroups on every CU; every stream compared with the oracle"""
+    n, T = 2048, 12
+    feats = distinct_feats(90000, n, T)
+    want = orc.synthesize_many(blob_f32, feats)
+    b = api.LPCNetBatch(n, blob_f32)
+    b.streams_per_workgroup = 4
+    got = b.synthesize(feats)
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+    b.close()
+
+
 @pytest.mark.parametrize("flavour", ["float", "int8"])
 def test_soak_1024_streams_two_seconds(flavour, hip_lib):
     """3.2e7 samples through the barrier-free index hand-off at full occupancy: 1024 distinct streams x 200 frames in one

@@ -47,7 +47,18 @@ def test_two_workgroups_per_cu_variants_stay_out_of_scratch_in_the_loop(tmp_path
         assert r["int8"] and r["NW"] == 32 and r["vgpr"] <= 128 and r["scratch_insts_in_sample_loop"] == 0, r
 
 
-def test_fast_fmac_dpp_hazards(rows):
+def test_fast_fmac_dpp_hazards(rows, tmp_path_factory):
+    """the hand-written v_fmac_f32_dpp of FAST float GRU-B sits inside inline assembly, where LLVM's hazard recogniser does not
+    look: VALU-write -> DPP-read (2 slots, register ranges included) and EXEC-write -> DPP (5 slots) are checked on the
+    assembly of every streams-per-workgroup value (S = 1 and 2 were unchecked)."""
+    import kernel_resources as kr
     for key, r in rows.items():
         if key[2] and not key[1]:
             assert r["fmac_dpp"] >= 16 and r["dpp_hazard_violations"] == 0, key     # (GRU-B's split loop; GRU-A's items use the matrix pipe)
+    for sv in (1, 2):
+        path = str(tmp_path_factory.mktemp(f"asm_s{sv}") / f"sample_s{sv}.s")
+        kr.compile_asm(sv, path)
+        fast_float = [r for r in kr.analyse(path) if r["fast"] and not r["int8"]]
+        assert len(fast_float) == 6
+        for r in fast_float:
+            assert r["fmac_dpp"] >= 16 and r["dpp_hazard_violations"] == 0, (sv, r["NW"], r["dpp_hazard_violations"])

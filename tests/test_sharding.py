@@ -36,15 +36,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_streams, T, q):
+def _worker(rank, world, port, n_streams, T, q, engine=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from oracle import orc                      # the CPU stand-in for the per-rank engine in this test
         first, count = shard.partition(n_streams, rank, world)
         blob = synth.blob_bytes(synth.make_model())
-        om = orc.OracleModel(blob)
-        pcm = np.stack([om.new_state().synthesize(synth.make_features(1000 + s, T)) for s in range(first, first + count)])
+        feats = np.stack([synth.make_features(1000 + s, T) for s in range(first, first + count)])
+        if engine:                                  # the HIP engine itself, one batch per rank (all ranks on device 0 here)
+            from lpcnet_amd import api
+            b = api.LPCNetBatch(count, blob, device=0)
+            pcm = b.synthesize(feats)
+            b.close()
+        else:
+            from oracle import orc                  # CPU-only run: the oracle stands in for the per-rank engine
+            om = orc.OracleModel(blob)
+            pcm = np.stack([om.new_state().synthesize(f) for f in feats])
         # control plane only: barrier + max of a local time + total of produced samples
         dist.barrier()
         t = torch.tensor([float(rank + 1)])
@@ -61,12 +68,12 @@ def _worker(rank, world, port, n_streams, T, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharding_reproduces_single_process():
-    n_streams, T, world = 3, 4, 2
+def _two_ranks(n_streams, T, engine):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, T, q, engine)) for r in range(world)]
     for p in procs:
         p.start()
     tmax, total, full = q.get(timeout=120)
@@ -78,3 +85,14 @@ def test_two_rank_sharding_reproduces_single_process():
     om = orc.OracleModel(synth.blob_bytes(synth.make_model()))
     want = np.stack([om.new_state().synthesize(synth.make_features(1000 + s, T)) for s in range(n_streams)])
     assert np.array_equal(full, want)
+
+
+def test_two_rank_sharding_reproduces_single_process():
+    _two_ranks(3, 4, engine=False)
+
+
+@pytest.mark.gpu
+def test_two_rank_sharding_on_the_engine():
+    """the same two gloo ranks with the HIP ENGINE as the per-rank worker (both on device 0: the boxes have one GPU),
+    7 streams so that the shards are uneven; checked against the oracle"""
+    _two_ranks(7, 6, engine=True)

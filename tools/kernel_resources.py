@@ -88,10 +88,15 @@ def analyse(asm_path):
             m = re.match(r"v_fmac_f32_dpp (v\d+), (v\d+),", ins)
             if not m:
                 continue
-            src = m.group(2)
-            for prev in insts[max(0, k - 2):k]:
-                pm = re.match(r"(v_\w+) (v\d+|v\[\d+:\d+\])", prev)
-                if pm and not prev.startswith("v_fmac_f32_dpp") and pm.group(2) == src:
+            src = int(m.group(2)[1:])
+            for prev in insts[max(0, k - 2):k]:             # VALU write -> DPP read of the same VGPR: 2 wait states
+                pm = re.match(r"(v_\w+) (?:v(\d+)|v\[(\d+):(\d+)\])", prev)
+                if pm and not prev.startswith("v_fmac_f32_dpp"):
+                    lo, hi = (int(pm.group(2)),) * 2 if pm.group(2) else (int(pm.group(3)), int(pm.group(4)))
+                    if lo <= src <= hi:                     # (a register RANGE that contains the DPP source counts too)
+                        dpp_viol += 1
+            for prev in insts[max(0, k - 5):k]:             # EXEC write -> DPP: 5 wait states
+                if re.match(r"v_cmpx", prev) or re.match(r"s_\w+ exec(_lo|_hi)?,", prev) or re.match(r"s_\w+saveexec", prev):
                     dpp_viol += 1
         total = sum(1 for ln in body if re.search(r"\bscratch_(load|store)", ln))
         rec = dict(name=name, **info, **meta.get(name, {}), scratch_insts=total, scratch_insts_in_sample_loop=in_loop, sample_loop_asm_lines=loop_lines,
