@@ -51,7 +51,8 @@ struct lpcn_engine {
 struct lpcn_batch_dev {
     lpcn_engine *e = nullptr;
     int n = 0, max_chunk = 0, S = 0, frame_len = LPCN_FRAME_SIZE;
-    bool S_auto = true;                // streams per workgroup follow the cost model (re-evaluated when the arithmetic flavour changes)
+    bool S_auto = true;                // streams per workgroup are chosen by the engine (measured on this batch, see autotune_streams_per_wg)
+    bool tuned = false;                // ... and have been measured for the current arithmetic flavour
     bool pack2 = false;                // 128-VGPR variant: two workgroups per CU (int8, <= 32 items per lane, more workgroups than CUs)
     lpcn_stream_state *d_state = nullptr;
     int *d_fc_base = nullptr;
@@ -417,14 +418,14 @@ extern "C" int lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b) { return b
 // the engine's arithmetic flavour changed: re-run the cost model unless the caller pinned the value
 extern "C" int lpcn_batch_dev_retune(lpcn_batch_dev *b)
 {
-    if (b->S_auto) b->S = auto_streams_per_wg(b->e, b->n);
+    if (b->S_auto) { b->S = auto_streams_per_wg(b->e, b->n); b->tuned = false; }      // measured again at the next run
     b->pack2 = use_pack2(b->e, b->n, b->S);
     return 0;
 }
 extern "C" int lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s)
 {
     b->S_auto = s == 0;
-    if (s == 0) s = auto_streams_per_wg(b->e, b->n);
+    if (s == 0) { s = auto_streams_per_wg(b->e, b->n); b->tuned = false; }
     if (s != 1 && s != 2 && s != 4) { snprintf(g_err, sizeof(g_err), "streams per workgroup must be 1, 2 or 4"); return LPCN_E_ARG; }
     b->S = s;
     b->pack2 = use_pack2(b->e, b->n, b->S);
@@ -488,6 +489,54 @@ static int launch_frames(lpcn_batch_dev *b, hipStream_t st, const float *d_feat,
                                      b->d_state, b->d_fc_base, b->d_cond, b->d_cond_a, b->d_cond_b, b->d_lpc, g_err, sizeof(g_err));
 }
 
+// Streams per workgroup, measured instead of looked up (the table in auto_streams_per_wg holds THIS model's step
+// times; a denser / sparser blob or another item-count variant has other optima).  Before the first run of a batch whose
+// value is not pinned, each candidate S runs two live frames (one to warm up, one timed with HIP events) on the batch's own
+// buffers -- zeroed frame products, the stream states saved and restored around it -- and the fastest wins.  ~6 launches of
+// a few ms, once per batch and arithmetic flavour; LPCNET_HIP_NO_AUTOTUNE=1 keeps the table value.
+static int autotune_streams_per_wg(lpcn_batch_dev *b, hipStream_t st)
+{
+    b->tuned = true;
+    const char *off = getenv("LPCNET_HIP_NO_AUTOTUNE");
+    if ((off && *off == '1') || b->n < 2) return 0;           // (one stream: one workgroup whatever S is)
+    const int nf = 2 < b->max_chunk ? 2 : b->max_chunk;
+    int rc = 0;
+    lpcn_stream_state *saved = nullptr;
+    short *pcm = nullptr;                                    // (a buffer of its own: the caller may be holding the staging buffer's address)
+    HIP_TRY(hipMalloc((void **)&saved, sizeof(lpcn_stream_state) * b->n));
+    if (hipMalloc((void **)&pcm, sizeof(short) * (size_t)b->n * nf * LPCN_FRAME_SIZE) != hipSuccess) { (void)hipFree(saved); snprintf(g_err, sizeof(g_err), "auto-tune: hipMalloc failed"); return LPCN_E_HIP; }
+    auto done = [&](int code) { (void)hipFree(saved); (void)hipFree(pcm); return code; };
+    std::vector<int> fc((size_t)b->n, LPCN_FEATURES_DELAY + 3);                     // every stream live
+    if (hipMemcpyAsync(saved, b->d_state, sizeof(lpcn_stream_state) * b->n, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemsetAsync(b->d_cond_a, 0, sizeof(float) * (size_t)b->n * nf * LPCN_ROWS_A, st) != hipSuccess ||
+        hipMemsetAsync(b->d_cond_b, 0, sizeof(float) * (size_t)b->n * nf * LPCN_ROWS_B, st) != hipSuccess ||
+        hipMemsetAsync(b->d_lpc, 0, sizeof(float) * (size_t)b->n * nf * LPCN_LPC_ORDER, st) != hipSuccess ||
+        hipMemcpyAsync(b->d_fc_base, fc.data(), sizeof(int) * b->n, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { snprintf(g_err, sizeof(g_err), "auto-tune: buffer setup failed"); return done(LPCN_E_HIP); }
+    const int keepS = b->S;
+    const bool keepP = b->pack2;
+    int best = keepS;
+    float best_ms = -1.f;
+    for (int S = 1; S <= 4; S *= 2) {
+        b->S = S; b->pack2 = use_pack2(b->e, b->n, S);
+        float ms = 0.f;
+        for (int pass = 0; pass < 2 && !rc; ++pass) {
+            if (hipEventRecord(b->ev[1], st) != hipSuccess) rc = LPCN_E_HIP;
+            if (!rc) rc = launch_sample(b, st, pcm, (size_t)nf * LPCN_FRAME_SIZE, nf, 0, true);
+            if (!rc && (hipEventRecord(b->ev[2], st) != hipSuccess || hipEventSynchronize(b->ev[2]) != hipSuccess ||
+                        hipEventElapsedTime(&ms, b->ev[1], b->ev[2]) != hipSuccess)) rc = LPCN_E_HIP;
+        }
+        if (rc) break;
+        if (best_ms < 0.f || ms < best_ms) { best_ms = ms; best = S; }
+    }
+    // the measurement ran on the real state: put it back
+    if (hipMemcpyAsync(b->d_state, saved, sizeof(lpcn_stream_state) * b->n, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) rc = rc ? rc : LPCN_E_HIP;
+    if (rc) { b->S = keepS; b->pack2 = keepP; return done(rc); }
+    b->S = best; b->pack2 = use_pack2(b->e, b->n, best);
+    return done(0);
+}
+
 extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, int feat_stride,
                                   short *d_pcm, int n_frames, int preload, void *hip_stream)
 {
@@ -498,6 +547,7 @@ extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, in
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->e->stream;
     float tf = 0.f, ts = 0.f;
     { int rco = order_begin(b, st); if (rco) return rco; }
+    if (b->S_auto && !b->tuned) { int rct = autotune_streams_per_wg(b, st); if (rct) return rct; }
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
         if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
@@ -641,6 +691,7 @@ extern "C" int lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond
     if (rc) return rc;
     hipStream_t st = b->e->stream;
     if ((rc = order_begin(b, st))) return rc;
+    if (b->S_auto && !b->tuned && (rc = autotune_streams_per_wg(b, st))) return rc;
     if (preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pcm, npcm * sizeof(short), hipMemcpyHostToDevice, st));
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;

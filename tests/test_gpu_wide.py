@@ -248,3 +248,35 @@ def test_sharded_batch_in_c(blob_f32, golden, hip_lib):
     assert np.array_equal(d_p.cpu().numpy(), want[sh[1][0]:sh[1][0] + sh[1][1]])
     assert s_one.frame_count == T
     b.close(); one.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(densities=(0.07, 0.07, 0.25)), dict(flavour="int8")], ids=["default", "denseA", "int8"])
+def test_streams_per_workgroup_is_measured_not_looked_up(kw, hip_lib):
+    """the streams-per-workgroup choice must come from THIS model (a denser GRU-A runs another item-count
+    variant with other step times): the engine times S = 1, 2, 4 on the batch itself before its first run.  The chosen
+    value has to be (within noise) the fastest of the three when each is pinned, the states must be untouched by the
+    measurement (bit-exact output afterwards), and a pinned value must stay pinned."""
+    blob = synth.blob_bytes(synth.make_model(**kw))
+    n, T = 1024, 6
+    feats = distinct_feats(95000, n, T)
+    auto = api.LPCNetBatch(n, blob)
+    pcm_auto = auto.synthesize(feats)
+    chosen = auto.streams_per_workgroup
+    auto.close()
+    times = {}
+    for S in (1, 2, 4):
+        b = api.LPCNetBatch(n, blob)
+        b.streams_per_workgroup = S
+        b.enable_timing(True)
+        b.synthesize(feats)                                  # warm-up
+        b.reset()
+        out = b.synthesize(feats)
+        times[S] = b.last_timing()[0]
+        assert b.streams_per_workgroup == S
+        if S == chosen:
+            assert np.array_equal(out, pcm_auto)             # the auto-tuned batch produced exactly what a pinned one does
+        b.close()
+    assert times[chosen] <= 1.08 * min(times.values()), (chosen, times)
+    pick = [0, 257, 1023]
+    want = orc.synthesize_many(blob, feats[pick])
+    assert first_mismatch(pcm_auto[pick], want) is None
