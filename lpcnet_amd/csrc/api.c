@@ -205,10 +205,15 @@ static int packet_to_features(float feat[4][NB_TOTAL_FEATURES], float *vq_mem, c
 
 /* ---- model registry for the single-stream API ------------------------------------------------
  * One slot per distinct weight blob (the registry keeps its own copy: dedupe compares the bytes, and a slot can
- * rebuild its device side at any time).  Slots live until process exit; lpcnet_hip_shutdown() only releases the
- * device resources, so a state bound before the shutdown simply re-creates them at its next call. */
+ * rebuild its device side at any time).  lpcnet_hip_shutdown() only releases the device resources, so a state bound
+ * before the shutdown simply re-creates them at its next call.  When all MAX_MODELS slots are taken, binding another
+ * blob evicts the least recently used slot that is not in a call (states are PODs that may be copied or dropped at
+ * will, so there is nothing to count references with); a state still holding the evicted handle stops with a message. */
 typedef struct {
     int used;
+    unsigned gen;                     /* bumped when the slot is evicted: a state's handle carries the generation it was bound with */
+    unsigned long last_use;           /* g_use_clock at the last bind / run (least recently used slot is evicted when the table is full) */
+    int pins;                         /* callers between "slot chosen" and "run_lock taken" (g_lock protects it) */
     unsigned char *blob; int len; uint64_t hash;
     lpcn_engine *engine;
     lpcn_batch_dev *dev;              /* 1 stream */
@@ -220,8 +225,12 @@ typedef struct {
 #define MAX_MODELS 16
 static registry_entry g_reg[MAX_MODELS];
 static int g_device = -1;             /* device of the single-stream API: lpcnet_hip_set_device(), $LPCNET_HIP_DEVICE, else 0 */
-static int g_default_model = -1;      /* registry slot of the process-default model, -1 = not resolved yet */
-static int g_default_tried;
+static int g_default_model = -1;      /* handle of the process-default model, -1 = not resolved yet */
+static unsigned long g_use_clock;
+/* A state's model handle: slot in the low byte, the slot's generation above it (a POD state cannot be told that its
+ * model went away; a stale handle is detected instead and stops with a message). */
+#define HANDLE(slot) ((int)(((g_reg[slot].gen & 0x7FFFFFu) << 8) | (unsigned)(slot)))
+static int handle_slot(int h) { const int slot = h & 0xFF; return (h >= 0 && slot < MAX_MODELS && g_reg[slot].used && HANDLE(slot) == h) ? slot : -1; }
 
 static uint64_t fnv1a(const unsigned char *p, int n)
 {
@@ -264,19 +273,37 @@ static int registry_materialize(registry_entry *r)
     return 0;
 }
 
-/* (g_lock held) slot of this blob, new or existing; -1 on a malformed blob / no device / table full */
+/* (g_lock held) handle of this blob's slot, new or existing; -1 on a malformed blob / no device / every slot busy */
 static int registry_bind(const unsigned char *blob, int len)
 {
     const uint64_t h = fnv1a(blob, len);
     int slot = -1;
     for (int i = 0; i < MAX_MODELS; i++) {
-        if (g_reg[i].used && g_reg[i].len == len && g_reg[i].hash == h && memcmp(g_reg[i].blob, blob, (size_t)len) == 0)
-            return registry_materialize(&g_reg[i]) == 0 ? i : -1;
+        if (g_reg[i].used && g_reg[i].len == len && g_reg[i].hash == h && memcmp(g_reg[i].blob, blob, (size_t)len) == 0) {
+            g_reg[i].last_use = ++g_use_clock;
+            return registry_materialize(&g_reg[i]) == 0 ? HANDLE(i) : -1;
+        }
         if (!g_reg[i].used && slot < 0) slot = i;
     }
-    if (slot < 0) { set_err("too many distinct models bound through lpcnet_load_model"); return -1; }
+    if (slot < 0) {                                          /* table full: evict the least recently used slot that nobody is running on */
+        for (int i = 0; i < MAX_MODELS; i++)
+            if (__atomic_load_n(&g_reg[i].pins, __ATOMIC_SEQ_CST) == 0 && i != (g_default_model & 0xFF) && (slot < 0 || g_reg[i].last_use < g_reg[slot].last_use) &&
+                pthread_mutex_trylock(&g_reg[i].run_lock) == 0) {
+                if (slot >= 0) pthread_mutex_unlock(&g_reg[slot].run_lock);
+                slot = i;
+            }
+        if (slot < 0) { set_err("too many distinct models in use at once through lpcnet_load_model"); return -1; }
+        registry_entry *v = &g_reg[slot];
+        if (v->dev) { lpcn_batch_dev_destroy(v->dev); lpcn_engine_destroy(v->engine); }
+        free(v->blob);
+        const unsigned gen = v->gen + 1;
+        pthread_mutex_unlock(&v->run_lock);
+        pthread_mutex_destroy(&v->run_lock);
+        memset(v, 0, sizeof(*v));
+        v->gen = gen;
+    }
     registry_entry *r = &g_reg[slot];
-    memset(r, 0, sizeof(*r));
+    { const unsigned gen = r->gen; memset(r, 0, sizeof(*r)); r->gen = gen; }
     r->blob = (unsigned char *)malloc((size_t)len);
     if (!r->blob) { set_err("out of memory"); return -1; }
     memcpy(r->blob, blob, (size_t)len);
@@ -284,7 +311,8 @@ static int registry_bind(const unsigned char *blob, int len)
     if (registry_materialize(r) != 0) { free(r->blob); r->blob = NULL; return -1; }
     pthread_mutex_init(&r->run_lock, NULL);
     r->used = 1;
-    return slot;
+    r->last_use = ++g_use_clock;
+    return HANDLE(slot);
 }
 
 /* Device resources of the single-stream API are released; bound states stay valid and re-create them on demand. */
@@ -307,7 +335,7 @@ int lpcnet_hip_set_default_model(const unsigned char *data, int len)
     if (!data || len <= 0) { set_err("lpcnet_hip_set_default_model: bad arguments"); return -1; }
     pthread_mutex_lock(&g_lock);
     const int id = registry_bind(data, len);
-    if (id >= 0) { g_default_model = id; g_default_tried = 1; }
+    if (id >= 0) g_default_model = id;
     pthread_mutex_unlock(&g_lock);
     return id >= 0 ? 0 : -1;
 }
@@ -315,14 +343,19 @@ int lpcnet_hip_set_default_model(const unsigned char *data, int len)
 /* (g_lock held) the process-default model: explicit, else $LPCNET_HIP_MODEL, else ./weights_blob.bin */
 static int default_model_locked(void)
 {
-    if (g_default_model >= 0 || g_default_tried) return g_default_model;
-    g_default_tried = 1;
+    if (handle_slot(g_default_model) >= 0) return g_default_model;
+    g_default_model = -1;
+    /* (a failed lookup is not remembered: the file may appear, or the working directory change, before the next call) */
     const char *path = getenv("LPCNET_HIP_MODEL");
+    const int from_cwd = !(path && *path);
     long len = 0;
-    unsigned char *buf = read_file(path && *path ? path : "weights_blob.bin", &len);
+    unsigned char *buf = read_file(from_cwd ? "weights_blob.bin" : path, &len);
     if (!buf) return -1;
     if (len > 0 && len < 0x7FFFFFFF) g_default_model = registry_bind(buf, (int)len);
     free(buf);
+    if (g_default_model >= 0 && from_cwd && !getenv("LPCNET_HIP_QUIET"))
+        fprintf(stderr, "lpcnet_hip: no model given (lpcnet_load_model / lpcnet_hip_set_default_model / $LPCNET_HIP_MODEL): using ./weights_blob.bin "
+                        "from the current directory, like the reference's demo does (src/lpcnet_demo.c:113)\n");
     return g_default_model;
 }
 
@@ -393,23 +426,37 @@ int lpcnet_hip_decoder_load_model(LPCNetDecState *st, const unsigned char *data,
 /* The registry slot this state runs on, locked for one device round trip (unlock with release_entry). */
 static registry_entry *acquire_entry(LPCNetState *st, const char *who)
 {
-    pthread_mutex_lock(&g_lock);
-    int id = (st->magic == LPCN_MAGIC) ? st->model_id : -1;
-    if (id < 0 || id >= MAX_MODELS || !g_reg[id].used) {
-        id = default_model_locked();
-        if (id >= 0 && st->magic == LPCN_MAGIC) st->model_id = id;
+    for (;;) {
+        pthread_mutex_lock(&g_lock);
+        int h = (st->magic == LPCN_MAGIC) ? st->model_id : -1;
+        if (h >= 0 && handle_slot(h) < 0) {
+            pthread_mutex_unlock(&g_lock);
+            fprintf(stderr, "%s: the model bound to this state was evicted (more than %d distinct models bound in this process); "
+                            "call lpcnet_load_model again\n", who, MAX_MODELS);
+            abort();
+        }
+        if (h < 0) {
+            h = default_model_locked();
+            if (h >= 0 && st->magic == LPCN_MAGIC) st->model_id = h;
+        }
+        const int id = handle_slot(h);
+        if (id < 0 || registry_materialize(&g_reg[id]) != 0) {
+            pthread_mutex_unlock(&g_lock);
+            fprintf(stderr, "%s: no model bound to this state and no default model (lpcnet_load_model, lpcnet_hip_set_default_model, "
+                            "$LPCNET_HIP_MODEL or ./weights_blob.bin): %s; the HIP engine has no built-in model and no CPU fallback\n",
+                    who, tl_err[0] ? tl_err : "none found");
+            abort();
+        }
+        registry_entry *r = &g_reg[id];
+        r->last_use = ++g_use_clock;
+        __atomic_add_fetch(&r->pins, 1, __ATOMIC_SEQ_CST);   /* keeps the slot from being evicted while we wait for it */
+        pthread_mutex_unlock(&g_lock);                       /* (other models, the decoder's packet unpacking, lpcnet_load_model go on meanwhile) */
+        pthread_mutex_lock(&r->run_lock);
+        /* (lock order is g_lock -> run_lock everywhere, so g_lock is not taken again here: the pin is dropped atomically) */
+        __atomic_sub_fetch(&r->pins, 1, __ATOMIC_SEQ_CST);
+        if (__atomic_load_n(&r->dev, __ATOMIC_SEQ_CST) != NULL) return r;     /* lpcnet_hip_shutdown() may have released the device side while we waited */
+        pthread_mutex_unlock(&r->run_lock);
     }
-    if (id < 0 || registry_materialize(&g_reg[id]) != 0) {
-        pthread_mutex_unlock(&g_lock);
-        fprintf(stderr, "%s: no model bound to this state and no default model (lpcnet_load_model, lpcnet_hip_set_default_model, "
-                        "$LPCNET_HIP_MODEL or ./weights_blob.bin): %s; the HIP engine has no built-in model and no CPU fallback\n",
-                who, tl_err[0] ? tl_err : "none found");
-        abort();
-    }
-    registry_entry *r = &g_reg[id];
-    pthread_mutex_lock(&r->run_lock);
-    pthread_mutex_unlock(&g_lock);
-    return r;
 }
 static void release_entry(registry_entry *r) { pthread_mutex_unlock(&r->run_lock); }
 

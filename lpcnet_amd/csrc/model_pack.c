@@ -6,6 +6,7 @@
  * same failure condition (-> lpcnet_load_model returns -1).  The register/LDS packings built at
  * the end are new: they exist only because the sample loop keeps GRU-A resident in VGPRs.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "lpcnet_engine.h"

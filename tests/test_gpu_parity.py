@@ -6,6 +6,7 @@ reference's accumulation order without FMA -- also every float state are compare
 (tolerance 0; north_star allows +-1 mu-law level, which free-running chaotic synthesis cannot use:
 SURVEY.md fact 8)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -479,3 +480,32 @@ def test_off_grid_float_model(kw, hip_lib):
             _, _, ga, gb = states[s].nnet_state()
             assert np.array_equal(np.array(st.gru_a, np.float32), ga) and np.array_equal(np.array(st.gru_b, np.float32), gb)
         b.close()
+
+
+def test_registry_evicts_least_recently_used_model_and_detects_stale_handles(hip_lib):
+    """ADVICE r2: the single-stream registry has 16 slots.  A 17th distinct blob used to fail for the rest of the process;
+    now it evicts the least recently used slot, the evicted blob can be bound again, states of models that are still
+    resident keep working bit for bit, and a state whose model was evicted is detected (it stops with a message instead
+    of silently running another model) -- checked in a child process because that path aborts."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from lpcnet_amd import api, synth
+        feats = synth.make_features(1000, 4)
+        run = lambda st: np.concatenate([st.synthesize(f) for f in feats])
+        blobs = [synth.blob_bytes(synth.make_model(seed=2000 + i)) for i in range(18)]
+        first = api.LPCNetState(blobs[0])
+        want0 = run(first)
+        states = [api.LPCNetState(b) for b in blobs[1:17]]         # 17 distinct blobs in total: slot of blob 0 (least recently used) is evicted
+        for st in states[:2]:
+            run(st)
+        again = api.LPCNetState(blobs[0])                          # binding the evicted blob again works (evicts another idle slot)
+        assert np.array_equal(run(again), want0) and np.any(want0 != 0)
+        print("REBOUND-OK", flush=True)
+        run(first)                                            # stale handle: must stop loudly
+        print("NOT-REACHED", flush=True)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "REBOUND-OK" in r.stdout and "NOT-REACHED" not in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    assert r.returncode != 0 and "evicted" in r.stderr
