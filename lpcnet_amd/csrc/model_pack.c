@@ -201,11 +201,14 @@ static int pack_gru_a(lpcn_model_host *m)
         g[i].group = i; g[i].count = *idx++; g[i].pos = idx; g[i].first_block = blk;
         idx += g[i].count; blk += g[i].count;
     }
-    const int deal2 = !m->is_int8;                        /* float blobs: split candidate chains (see deal_wave_cost) */
+    const char *old_i8 = getenv("LPCN_DEAL_I8_OLD");      /* tools: "1" = int8 blobs dealt without early heads (the round-2 scheme) */
+    const int deal2 = !m->is_int8 || !(old_i8 && old_i8[0] == '1');      /* split candidate chains (see deal_wave_cost) */
     {
-        const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
-        g_deal_eh = (eh && *eh) ? atoi(eh) : 20;
+        const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (float default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
+        g_deal_eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : 20);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
         if (g_deal_eh < 0) g_deal_eh = 0;
+        if (m->is_int8) { g_deal_tg = 4200; g_deal_t0a = 1600; g_deal_t0b = 900; g_deal_ci = 250; g_deal_cu = 220; }
+        else            { g_deal_tg = 5000; g_deal_t0a = 1600; g_deal_t0b = 900; g_deal_ci = 395; g_deal_cu = 320; }
         const char *cm = getenv("LPCN_DEAL_COST");        /* tools: "TG,T0a,T0b,CI,CU" of deal_wave_cost */
         if (cm && *cm) sscanf(cm, "%d,%d,%d,%d,%d", &g_deal_tg, &g_deal_t0a, &g_deal_t0b, &g_deal_ci, &g_deal_cu);
     }
@@ -288,7 +291,7 @@ static int pack_gru_a(lpcn_model_host *m)
     if (deal2) {                                    /* float blobs: the enumeration replaces the assignment above */
         int nc = 0, w2[NSLOT];
         while (nc < NSLOT && slot_allh[nc]) nc++;
-        static const int caps[] = {30, 32, 36, 40, 0};
+        static const int caps[] = {30, 32, 36, 40, 48, 64, 0};
         int done = 0;
         for (const int *c = caps; *c && !done; c++) {
             if (slot_max[0] > *c) continue;
@@ -520,7 +523,9 @@ static int selftest_i8(const lpcn_model_host *m)
             for (int lane = 0; lane < 64; lane++) {
                 int row = m->pk_a_row[(wv * LPCN_MAX_SLOTS + k) * 64 + lane];
                 if (row < 0) continue;
-                for (int j = m->pk_a_bound[wv][k]; j < m->pk_a_bound[wv][k + 1]; j++) {
+                const int j0 = m->pk_a_bound[wv][k], head = k == 0 ? m->pk_a_head[wv] : 0;     /* slot 0's early items sit end-aligned */
+                for (int jj = j0 - head; jj < m->pk_a_bound[wv][k + 1]; jj++) {
+                    const int j = jj < j0 ? m->nw + (jj - j0) : jj;
                     size_t item = ((size_t)wv * m->nw + j) * 64 + lane;
                     signed char q[4];
                     memcpy(q, &m->pk_a_wq[item], 4);

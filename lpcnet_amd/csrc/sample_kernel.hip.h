@@ -361,11 +361,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row[1] >= 0) != 0ull ? 2 : 0) |
                                                         (__ballot(row[2] >= 0) != 0ull ? 4 : 0));
     const bool has2 = (has_slot & 4) != 0;
-    // Float blobs: waves that do not run GRU-B compute the HEAD of their candidate slot's chains (the first `hl` blocks of every
+    // Waves that do not run GRU-B compute the HEAD of their candidate slot's chains (the first `hl` blocks of every
     // row of slot 0, stored end-aligned at items [NW - hl, NW) by model_pack.c) one sample ahead, in GRU-B's shadow, and park
-    // the partial sums in the rows' sm_pre cells; the slot then starts from those in the next sample.
-    const int hl = I8 ? 0 : __builtin_amdgcn_readfirstlane(as_global(Ap->a_head)[tid0 >> 6]);
-    const bool early_wave = !I8 && hl > 0;                  // wave-uniform (model_pack.c deals heads to waves 4..7 only: never a GRU-B wave)
+    // the partial sums (the raw accumulators: scaled by 128*127 for int8 blobs, an int32 pattern in FAST) in the rows' sm_pre
+    // cells; the slot then starts from those in the next sample.
+    const int hl = __builtin_amdgcn_readfirstlane(as_global(Ap->a_head)[tid0 >> 6]);
+    const bool early_wave = hl > 0;                          // wave-uniform (model_pack.c deals heads to waves 4..7 only: never a GRU-B wave)
 
     // ------------------------------------------------------------------ LDS residents -------
     {
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     const float g = ((pre_c[slot][s] + ge[set][0][s]) + ge[set][1][s]) + ge[set][2][s];
                     if (candidate && live_row) sm_inh[n * S + s] = g;
                     float v = candidate ? b : b + g;
-                    v = acc_start<I8, FAST>(v);
+                    if (!(k == 0 && early_wave)) v = acc_start<I8, FAST>(v);       // (a parked partial sum already is an accumulator)
                     if (to_acc) acc[s] = v; else if (live_row && park) sm_pre[r * S + s] = v;
                 }
             };
@@ -809,7 +810,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                 };
                 step(step, std::integral_constant<int, J0>{});
-                row_store(0);                                // park the partial sums
+                {                                            // park the partial sums as they are (no final scaling)
+                    int r = row[0];
+                    LPCN_REMAT_V(r);
+                    if (r >= 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc[s];
+                    }
+                }
             };
             if (early_wave && !head_ready) { run_head(); head_ready = true; }     // first sample of the launch only
             const int jend = b3;
@@ -1288,6 +1296,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         if constexpr (I8) smem[L::hBq + s * NB + lane] = (unsigned char)quant_s8(hnew);
                     }
                 }
+            }
+            if constexpr (I8 && FAST) {
+                // (FAST int8 splits GRU-B over all waves and its gate waves are 0, GB_W, 2 GB_W, ...: a wave can be both a gate
+                // wave and an early wave -- it computes its candidate heads behind the gate stage)
+                if (gate_wave && early_wave) run_head();
             }
             LPCN_PROF(11);     // GRU-B gates (gate waves) / early GRU-A slot (the others)
             __syncthreads();                                                   // B3

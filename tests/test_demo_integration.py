@@ -119,3 +119,60 @@ def test_demo_decode_on_default_model_and_codebooks(tmp_path, golden, hip_lib):
     packets = np.ascontiguousarray(golden["packets"], np.uint8)
     pcm = _run_demo(tmp_path, "float", ["-decode", "pk.bin", "out.pcm"], [("pk.bin", packets.tobytes()), ("ceps_codebooks.bin", cb_bytes)])
     assert np.array_equal(pcm, golden["packet_pcm_gf"].reshape(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("options", [0, 4, 2], ids=["causal", "causal+dc-filter", "codec"])
+def test_unmodified_reference_plc_runs_on_the_engine_bit_exact(options, hip_lib):
+    """SURVEY.md section 8f N3, end to end: the reference's packet-loss concealment (src/lpcnet_plc.c, compiled UNMODIFIED against
+    the engine's state layout, oracle/_ref/liblpcnet_plc_hip.so) drives the HIP engine through the internal entry points --
+    by-value state snapshots and rollbacks (src/lpcnet_plc.c:223-231,384-414), teacher forcing, deferred frame-network
+    queue, direct clearing of state members (:176-180) -- over a signal with lost frames, and must return sample for
+    sample what the reference's own generic-C build returns (oracle/_ref/liblpcnet_ref_gf.so: same PLC network, same
+    feature extraction, its own CPU LPCNet).  The PLC network is a seeded synthetic one (tests/tools/plc_synth.py)."""
+    import ctypes as C
+    import sys
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "liblpcnet_ref_gf.so")
+    plc_path = os.path.join(ROOT, "oracle", "_ref", "liblpcnet_plc_hip.so")
+    if not (os.path.exists(ref_path) and os.path.exists(plc_path)):
+        pytest.skip("oracle/_ref/liblpcnet_plc_hip.so / liblpcnet_ref_gf.so not built (needs the reference tree)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import plc_synth
+    from lpcnet_amd import api
+    blob = synth.blob_bytes(plc_synth.make_model_with_plc())
+    # the signal: 60 frames synthesised by the engine itself (speech-like), every 7th..9th frame lost
+    feats = synth.make_features(4242, 64)
+    b = api.LPCNetBatch(1, blob)
+    signal = b.synthesize(feats[None])[0, 4 * 160:]
+    b.close()
+    T = signal.size // 160
+    lost = [(t % 9) in (6, 7) or t in (20, 21, 22, 23) for t in range(T)]
+
+    def run(path):
+        lib = C.CDLL(path)
+        lib.lpcnet_plc_create.restype = C.c_void_p
+        lib.lpcnet_plc_create.argtypes = [C.c_int]
+        lib.lpcnet_plc_load_model.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.lpcnet_plc_update.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lpcnet_plc_conceal.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lpcnet_plc_destroy.argtypes = [C.c_void_p]
+        buf = C.create_string_buffer(blob, len(blob))         # must outlive the state (the reference keeps pointers into it)
+        st = lib.lpcnet_plc_create(options)
+        assert lib.lpcnet_plc_load_model(st, buf, len(blob)) == 0
+        out = np.zeros(T * 160, np.int16)
+        for t in range(T):
+            frame = np.ascontiguousarray(signal[t * 160:(t + 1) * 160]).copy()
+            if lost[t]:
+                lib.lpcnet_plc_conceal(st, frame.ctypes.data)
+            else:
+                lib.lpcnet_plc_update(st, frame.ctypes.data)
+            out[t * 160:(t + 1) * 160] = frame
+        lib.lpcnet_plc_destroy(st)
+        return out
+
+    want = run(ref_path)
+    got = run(plc_path)
+    concealed = np.concatenate([want[t * 160:(t + 1) * 160] for t in range(T) if lost[t]])
+    assert np.abs(concealed.astype(np.int32)).max() > 50      # the concealment really synthesised something
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (int(bad[0]) // 160, int(bad[0]) % 160, int(bad.size))
