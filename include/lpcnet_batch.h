@@ -55,6 +55,19 @@ LPCNET_EXPORT int lpcnet_batch_sync(LPCNetBatch *b);
  * (src/lpcnet.c:256-259,273): the first `preload` samples of every frame are read from pcm. */
 LPCNET_EXPORT int lpcnet_batch_synthesize_preload(LPCNetBatch *b, const float *features, int feat_stride, short *pcm,
                                                   int n_frames, int preload);
+/* ONE frame step with PER-STREAM arguments -- what a batched packet-loss concealment needs (src/lpcnet_plc.c drives each of
+ * its streams with lpcnet_synthesize_impl(N, preload), lpcnet_synthesize_tail_impl(N, preload) or nothing, depending on that
+ * stream's losses).  features [n_streams][feat_stride], pcm [n_streams][160]; per stream s:
+ *   mode[s] = 0  leave the stream alone
+ *   mode[s] = 1  frame network on features[s], then n_samples[s] samples      (lpcnet_synthesize_impl, src/lpcnet.c:273-277)
+ *   mode[s] = 2  n_samples[s] samples from the products of the stream's most recent mode-1 step
+ *                                                                          (lpcnet_synthesize_tail_impl, src/lpcnet.c:235-271)
+ *   n_samples[s] in 1..160; the first preload[s] <= n_samples[s] samples of pcm[s] are imposed on the synthesis filter
+ *   (teacher forcing, src/lpcnet.c:256-259) and returned unchanged; samples n_samples[s]..159 of pcm[s] are not touched.
+ * Streams with equal (mode, n_samples, preload) run together; results are bit-identical to driving each stream alone through
+ * the single-stream entry points.  Meant for occasional use (it compacts and scatters the groups), not for throughput. */
+LPCNET_EXPORT int lpcnet_batch_synthesize_step(LPCNetBatch *b, const float *features, int feat_stride, short *pcm,
+                                               const int *n_samples, const int *preload, const int *mode);
 /* Codec path: packets [n_streams][n_packets][8] -> pcm [n_streams][n_packets*640] (lpcnet_decode per stream) */
 LPCNET_EXPORT int lpcnet_batch_decode(LPCNetBatch *b, const unsigned char *packets, short *pcm, int n_packets);
 /* the same with device pointers (packets [n][n_packets][8], pcm [n][n_packets*640]), only enqueued on `hip_stream`

@@ -92,6 +92,7 @@ def load_library():
     L.lpcnet_batch_synthesize_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.lpcnet_batch_sync.argtypes = [vp]
     L.lpcnet_batch_synthesize_preload.argtypes = [vp, _f32p, C.c_int, _i16p, C.c_int, C.c_int]
+    L.lpcnet_batch_synthesize_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.lpcnet_batch_decode.argtypes = [vp, _u8p, _i16p, C.c_int]
     L.lpcnet_batch_decode_device.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lpcnet_batch_set_lpc_gamma.argtypes = [vp, C.c_float]
@@ -287,6 +288,18 @@ class LPCNetBatch:
             pcm = np.ascontiguousarray(preload_pcm, np.int16).copy()
             self._chk(self.L.lpcnet_batch_synthesize_preload(self.p, f.reshape(-1), stride, pcm.reshape(-1), T, preload), "synthesize_preload")
         return pcm
+
+    def synthesize_step(self, features: np.ndarray, pcm: np.ndarray, n_samples, preload, mode) -> np.ndarray:
+        """one frame step with per-stream (mode, n_samples, preload): include/lpcnet_batch.h lpcnet_batch_synthesize_step;
+        features (n, >=20), pcm (n, 160) int16 (in: the imposed samples; out: the synthesised ones)."""
+        f = np.ascontiguousarray(features, np.float32)
+        out = np.ascontiguousarray(pcm, np.int16).copy()
+        ns, pr, md = (np.ascontiguousarray(x, np.int32) for x in (n_samples, preload, mode))
+        assert f.shape[0] == self.n and out.shape == (self.n, LPCNET_FRAME_SIZE) and ns.size == pr.size == md.size == self.n
+        self._chk(self.L.lpcnet_batch_synthesize_step(self.p, f.ctypes.data_as(C.c_void_p), f.shape[1], out.ctypes.data_as(C.c_void_p),
+                                                      ns.ctypes.data_as(C.c_void_p), pr.ctypes.data_as(C.c_void_p), md.ctypes.data_as(C.c_void_p)),
+                  "lpcnet_batch_synthesize_step")
+        return out
 
     def synthesize_device(self, d_features_ptr: int, stride: int, d_pcm_ptr: int, n_frames: int, hip_stream: int = 0):
         self._chk(self.L.lpcnet_batch_synthesize_device(self.p, d_features_ptr, stride, d_pcm_ptr, n_frames, hip_stream or None), "synthesize_device")

@@ -760,6 +760,21 @@ int lpcnet_batch_synthesize_preload(LPCNetBatch *b, const float *features, int f
     return run_shards(b, &j);
 }
 
+/* one frame step with per-stream arguments (see include/lpcnet_batch.h); shards run one after the other */
+int lpcnet_batch_synthesize_step(LPCNetBatch *b, const float *features, int feat_stride, short *pcm,
+                                 const int *n_samples, const int *preload, const int *mode)
+{
+    NEED_MODEL(b);
+    if (!features || !pcm || !n_samples || !preload || !mode) { set_err("lpcnet_batch_synthesize_step: bad arguments"); return LPCN_E_ARG; }
+    for (int k = 0; k < b->n_shards; k++) {
+        const batch_shard *s = &b->sh[k];
+        int rc = lpcn_batch_dev_step_host(s->dev, features + (size_t)s->first * feat_stride, feat_stride, pcm + (size_t)s->first * LPCN_FRAME_SIZE,
+                                          n_samples + s->first, preload + s->first, mode + s->first);
+        if (rc) { take_engine_err(); return rc; }
+    }
+    return 0;
+}
+
 int lpcnet_batch_synthesize(LPCNetBatch *b, const float *features, int feat_stride, short *pcm, int n_frames)
 {
     return lpcnet_batch_synthesize_preload(b, features, feat_stride, pcm, n_frames, 0);

@@ -59,6 +59,9 @@ struct lpcn_batch_dev {
     float *d_cond_a = nullptr, *d_cond_b = nullptr, *d_lpc = nullptr, *d_cond = nullptr;
     float *d_feat = nullptr;           // staging for host-pointer runs / decoded feature vectors
     float *d_vq_mem = nullptr;         // [n][18] VQ memory of the codec path (src/lpcnet_private.h:52)
+    lpcn_stream_state *d_state_tmp = nullptr;   // per-stream-arguments step (lpcn_batch_dev_step_host): the compacted group's states
+    int *d_map = nullptr;              //   ... and its stream indices
+    float *d_keep_a = nullptr, *d_keep_b = nullptr, *d_keep_lpc = nullptr;   //   ... and every stream's most recent frame products
     float *d_hmir = nullptr;           // [stream slot][384] GRU-A state mirror read by GRU-B through the scalar cache (sample_kernel.hip.h: gb_scalar)
     unsigned char *d_packets = nullptr;
     size_t packets_cap = 0;
@@ -363,7 +366,7 @@ extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
     if (b->h_pin) (void)hipHostFree(b->h_pin);
     if (b->ev_last) (void)hipEventDestroy(b->ev_last);
     void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof,
-                    b->d_vq_mem, b->d_packets, b->d_hmir};
+                    b->d_vq_mem, b->d_packets, b->d_hmir, b->d_state_tmp, b->d_map, b->d_keep_a, b->d_keep_b, b->d_keep_lpc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : b->ev) if (ev) (void)hipEventDestroy(ev);
     delete b;
@@ -739,6 +742,106 @@ extern "C" int lpcn_batch_dev_run_frames_host(lpcn_batch_dev *b, const float *fe
         if (lpc) HIP_TRY(hipMemcpy2DAsync(lpc + (size_t)f0 * LPCN_LPC_ORDER, (size_t)n_frames * LPCN_LPC_ORDER * 4, b->d_lpc, (size_t)nf * LPCN_LPC_ORDER * 4,
                                           (size_t)nf * LPCN_LPC_ORDER * 4, b->n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+// ---- one frame step with PER-STREAM arguments (a batched packet-loss concealment needs it: src/lpcnet_plc.c calls
+// lpcnet_synthesize_impl(N = TRAINING_OFFSET, preload), lpcnet_synthesize_tail_impl(N, preload) and plain frames per
+// stream, depending on which of its streams lost a packet).  mode[s]: 0 = leave the stream alone, 1 = frame network on
+// features[s] + n_samples[s] samples (lpcnet_synthesize_impl, src/lpcnet.c:273-277), 2 = n_samples[s] samples from the
+// products of the stream's most recent frame (lpcnet_synthesize_tail_impl, src/lpcnet.c:235-271); the first preload[s]
+// samples of pcm[s] are imposed (teacher forcing).  Streams with equal (mode, n_samples, preload) form a group; a group is
+// compacted (states gathered by a small kernel, features / PCM on the host side), runs through the ordinary kernels and is
+// scattered back -- the hot kernels stay untouched; this path is meant for occasional use, not for throughput.
+__global__ void lpcn_state_move_kernel(lpcn_stream_state *dst, const lpcn_stream_state *src, const int *map, int count, int scatter)
+{
+    const int words = (int)(sizeof(lpcn_stream_state) / 4);
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const uint32_t *s = (const uint32_t *)(scatter ? &src[i] : &src[map[i]]);
+    uint32_t *d = (uint32_t *)(scatter ? &dst[map[i]] : &dst[i]);
+    for (int k = threadIdx.x; k < words; k += blockDim.x) d[k] = s[k];
+}
+__global__ void lpcn_rows_move_kernel(float *dst, const float *src, const int *map, int count, int width, int scatter)
+{
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const float *s = src + (size_t)(scatter ? i : map[i]) * width;
+    float *d = dst + (size_t)(scatter ? map[i] : i) * width;
+    for (int k = threadIdx.x; k < width; k += blockDim.x) d[k] = s[k];
+}
+
+extern "C" int lpcn_batch_dev_step_host(lpcn_batch_dev *b, const float *features, int feat_stride, short *pcm,
+                                        const int *n_samples, const int *preload, const int *mode)
+{
+    if (!features || !pcm || !n_samples || !preload || !mode || feat_stride < LPCN_NB_FEAT) { snprintf(g_err, sizeof(g_err), "bad step arguments"); return LPCN_E_ARG; }
+    for (int s = 0; s < b->n; ++s) {
+        if (mode[s] < 0 || mode[s] > 2) { snprintf(g_err, sizeof(g_err), "stream %d: mode must be 0, 1 or 2", s); return LPCN_E_ARG; }
+        if (mode[s] && (n_samples[s] < 1 || n_samples[s] > LPCN_FRAME_SIZE || preload[s] < 0 || preload[s] > n_samples[s])) {
+            snprintf(g_err, sizeof(g_err), "stream %d: n_samples must be 1..160 and preload 0..n_samples", s); return LPCN_E_ARG;
+        }
+    }
+    DeviceGuard guard(b->e->device);
+    int rc = ensure_staging(b, (size_t)b->n * LPCN_NB_FEAT, (size_t)b->n * LPCN_FRAME_SIZE);
+    if (rc) return rc;
+    hipStream_t st = b->e->stream;
+    if ((rc = order_begin(b, st))) return rc;
+    if (b->S_auto && !b->tuned && (rc = autotune_streams_per_wg(b, st))) return rc;
+#define ALX(ptr, bytes) if (!(ptr) && hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) failed", (size_t)(bytes)); return LPCN_E_HIP; }
+    ALX(b->d_state_tmp, sizeof(lpcn_stream_state) * b->n);
+    ALX(b->d_map, sizeof(int) * b->n);
+    if (!b->d_keep_a) {
+        ALX(b->d_keep_a, sizeof(float) * (size_t)b->n * LPCN_ROWS_A);
+        ALX(b->d_keep_b, sizeof(float) * (size_t)b->n * LPCN_ROWS_B);
+        ALX(b->d_keep_lpc, sizeof(float) * (size_t)b->n * LPCN_LPC_ORDER);
+        HIP_TRY(hipMemsetAsync(b->d_keep_a, 0, sizeof(float) * (size_t)b->n * LPCN_ROWS_A, st));
+        HIP_TRY(hipMemsetAsync(b->d_keep_b, 0, sizeof(float) * (size_t)b->n * LPCN_ROWS_B, st));
+        HIP_TRY(hipMemsetAsync(b->d_keep_lpc, 0, sizeof(float) * (size_t)b->n * LPCN_LPC_ORDER, st));
+    }
+#undef ALX
+    std::vector<char> done((size_t)b->n, 0);
+    std::vector<int> map;
+    std::vector<float> fc((size_t)b->n * LPCN_NB_FEAT);
+    std::vector<short> pc((size_t)b->n * LPCN_FRAME_SIZE);
+    const int keep_n = b->n, keep_len = b->frame_len;
+    lpcn_stream_state *const keep_state = b->d_state;
+    auto restore = [&]() { b->n = keep_n; b->frame_len = keep_len; b->d_state = keep_state; };
+    for (int s0 = 0; s0 < keep_n; ++s0) {
+        if (done[s0] || mode[s0] == 0) continue;
+        map.clear();
+        for (int s = s0; s < keep_n; ++s)
+            if (!done[s] && mode[s] == mode[s0] && n_samples[s] == n_samples[s0] && preload[s] == preload[s0]) { map.push_back(s); done[s] = 1; }
+        const int cnt = (int)map.size(), N = n_samples[s0], pre = preload[s0], md = mode[s0];
+        for (int i = 0; i < cnt; ++i) {
+            memcpy(&fc[(size_t)i * LPCN_NB_FEAT], features + (size_t)map[i] * feat_stride, sizeof(float) * LPCN_NB_FEAT);
+            memcpy(&pc[(size_t)i * LPCN_FRAME_SIZE], pcm + (size_t)map[i] * LPCN_FRAME_SIZE, sizeof(short) * LPCN_FRAME_SIZE);
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_map, map.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_feat, fc.data(), sizeof(float) * (size_t)cnt * LPCN_NB_FEAT, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_pcm, pc.data(), sizeof(short) * (size_t)cnt * LPCN_FRAME_SIZE, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lpcn_state_move_kernel, dim3(cnt), dim3(256), 0, st, b->d_state_tmp, (const lpcn_stream_state *)keep_state, (const int *)b->d_map, cnt, 0);
+        b->n = cnt; b->d_state = b->d_state_tmp; b->frame_len = N;
+        if (md == 1) {
+            rc = launch_frames(b, st, b->d_feat, LPCN_NB_FEAT, (size_t)LPCN_NB_FEAT, 1);
+            if (!rc) {      // remember the products per stream (a later tail-only step of the stream uses them)
+                hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(256), 0, st, b->d_keep_a, (const float *)b->d_cond_a, (const int *)b->d_map, cnt, LPCN_ROWS_A, 1);
+                hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_keep_b, (const float *)b->d_cond_b, (const int *)b->d_map, cnt, LPCN_ROWS_B, 1);
+                hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_keep_lpc, (const float *)b->d_lpc, (const int *)b->d_map, cnt, LPCN_LPC_ORDER, 1);
+            }
+        } else {
+            hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(256), 0, st, b->d_cond_a, (const float *)b->d_keep_a, (const int *)b->d_map, cnt, LPCN_ROWS_A, 0);
+            hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_cond_b, (const float *)b->d_keep_b, (const int *)b->d_map, cnt, LPCN_ROWS_B, 0);
+            hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_lpc, (const float *)b->d_keep_lpc, (const int *)b->d_map, cnt, LPCN_LPC_ORDER, 0);
+        }
+        if (!rc) rc = launch_sample(b, st, b->d_pcm, (size_t)LPCN_FRAME_SIZE, 1, pre, md == 1);
+        restore();
+        if (rc) return rc;
+        hipLaunchKernelGGL(lpcn_state_move_kernel, dim3(cnt), dim3(256), 0, st, keep_state, (const lpcn_stream_state *)b->d_state_tmp, (const int *)b->d_map, cnt, 1);
+        if (hipGetLastError() != hipSuccess) { snprintf(g_err, sizeof(g_err), "per-stream step: kernel launch failed"); return LPCN_E_HIP; }
+        HIP_TRY(hipMemcpyAsync(pc.data(), b->d_pcm, sizeof(short) * (size_t)cnt * LPCN_FRAME_SIZE, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < cnt; ++i) memcpy(pcm + (size_t)map[i] * LPCN_FRAME_SIZE, &pc[(size_t)i * LPCN_FRAME_SIZE], sizeof(short) * (size_t)N);
     }
     return 0;
 }

@@ -164,6 +164,12 @@ int  lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond_a, const 
 int  lpcn_batch_dev_run_frames_host(lpcn_batch_dev *b, const float *features, int feat_stride,
                                     float *cond_a, float *cond_b, float *lpc, int n_frames);
 
+/* One frame step with per-stream arguments (host pointers, see engine.hip): mode[s] 0 = skip, 1 = frame network + n_samples[s]
+ * samples, 2 = n_samples[s] samples from the stream's most recent frame products; preload[s] leading samples of pcm[s] imposed.
+ * features [n][feat_stride], pcm [n][160]. */
+int  lpcn_batch_dev_step_host(lpcn_batch_dev *b, const float *features, int feat_stride, short *pcm,
+                              const int *n_samples, const int *preload, const int *mode);
+
 /* Timing of the most recent run: kernel-only milliseconds measured with HIP events on the
  * stream the kernels were launched on (sample kernel, frame kernels). */
 int  lpcn_batch_dev_last_timing(lpcn_batch_dev *b, float *ms_sample, float *ms_frame);

@@ -509,3 +509,41 @@ def test_registry_evicts_least_recently_used_model_and_detects_stale_handles(hip
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert "REBOUND-OK" in r.stdout and "NOT-REACHED" not in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     assert r.returncode != 0 and "evicted" in r.stderr
+
+
+def test_batch_step_with_per_stream_arguments_like_a_batched_plc(blob_f32, hip_lib):
+    """VERDICT r2 (missing 5): the PLC's call pattern per frame is lpcnet_synthesize_impl(N = TRAINING_OFFSET, preload) /
+    lpcnet_synthesize_tail_impl(N, preload) / nothing, per stream (src/lpcnet_plc.c:224-239,308-320,405-421).
+    lpcnet_batch_synthesize_step takes (mode, n_samples, preload) PER STREAM: 12 streams, every call a different mix of
+    skipped streams, full / partial frames with and without teacher forcing and tail-only steps; each stream must equal the
+    oracle driven alone with the same calls, bit for bit, including the samples it must leave untouched."""
+    rng = np.random.default_rng(7)
+    n, calls = 12, 14
+    om = orc.OracleModel(blob_f32)
+    ost = [om.new_state() for _ in range(n)]
+    b = api.LPCNetBatch(n, blob_f32)
+    had_frame = [False] * n
+    for c in range(calls):
+        feats = np.stack([synth.make_features(5000 + 31 * c + s, 1)[0] for s in range(n)])
+        pcm_in = rng.integers(-3000, 3000, size=(n, 160)).astype(np.int16)
+        mode = rng.integers(0, 3, size=n)
+        if c < 3:
+            mode[:] = 1                                      # start-up frames for everybody
+        mode = np.where((mode == 2) & ~np.array(had_frame), 1, mode)
+        ns = rng.choice([160, 120, 40, 1, 77], size=n)
+        pre = np.array([int(rng.integers(0, k + 1)) if rng.random() < 0.6 else 0 for k in ns])
+        want = pcm_in.copy()
+        for s in range(n):
+            if mode[s] == 0:
+                continue
+            frame = want[s]
+            if mode[s] == 1:
+                ost[s].L.orc_synthesize(ost[s].p, np.ascontiguousarray(feats[s, :20]), frame, int(ns[s]), int(pre[s]))
+                had_frame[s] = True
+            else:
+                lpc, ca, cb = ost[s].frame_products()
+                ost[s].L.orc_synthesize_tail(ost[s].p, ca, cb, lpc, frame, int(ns[s]), int(pre[s]))
+        got = b.synthesize_step(feats, pcm_in, ns, pre, mode)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (c, bad[:4].tolist(), mode.tolist(), ns.tolist(), pre.tolist())
+    b.close()
