@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--fast", action="store_true",
                     help="FAST arithmetic (fused multiply-add / int32 accumulation like the reference's AVX2 builds): a separate, "
                          "non-bit-exact flavour; the headline is the default PARITY arithmetic")
+    ap.add_argument("--fp16-fc", action="store_true", help="with --fast: the sampler's dual FC in fp16 (BASELINE.json config 4's wording)")
     ap.add_argument("--int8", action="store_true",
                     help="BASELINE.json config 4: int8 (DOT_PROD) GRU-A/GRU-B weights, bit-exact vs the reference's generic int8 build "
                          "(default: float32 weights, the configuration the metric is quoted on)")
@@ -258,7 +259,7 @@ def main():
     if a.spw:
         batch.streams_per_workgroup = a.spw
     if a.fast:
-        batch.set_fast(True)
+        batch.set_fast(2 if a.fp16_fc else 1)
         a.check_streams = 0                                  # FAST is validated teacher-forced (tests/test_gpu_fast.py), not bit for bit
     # synthetic features: every stream of every rank has its own seeded feature file, resident in HBM
     feats = np.stack([synth.make_features(1000 + rank * n + s, F) for s in range(n)])
@@ -354,7 +355,7 @@ def main():
             "config": {"workload": f"{n} concurrent streams (each with its own feature file) per GPU x {F} frames ({F * 160} samples) per step, "
                                    + ("int8 GRU weights (v_dot4_i32_i8)" if a.int8 else "fp32 weights")
                                    + ", register-resident block-sparse GRU-A, "
-                                   + ("FAST arithmetic (FMA / int32 accumulation, not bit-exact)" if a.fast else "bit-exact (PARITY) arithmetic"),
+                                   + (("FAST arithmetic (FMA / int32 accumulation, not bit-exact)" + (", fp16 dual FC" if a.fp16_fc else "")) if a.fast else "bit-exact (PARITY) arithmetic"),
                        "arithmetic": "fast" if a.fast else "parity",
                        "streams_per_gpu": n, "frames_per_step": F, "streams_per_workgroup": batch.streams_per_workgroup,
                        "sharding": f"{world} x {n} independent streams, no data-path collective"},

@@ -84,7 +84,11 @@ LPCNET_EXPORT int lpcnet_batch_set_end2end(LPCNetBatch *b, int on);
  * generic-C build, results bit-identical to it.  1 = FAST: the arithmetic of the reference's own SIMD builds -- fused
  * multiply-add for float blobs (src/vec_avx.h:790-858), int32 block accumulation for int8 blobs (src/vec_avx.h:690-750) --
  * not bit-identical to any reference build (those differ among themselves as well); tests/test_gpu_fast.py keeps its
- * teacher-forced deviation inside the reference's own AVX2-vs-generic envelope. */
+ * teacher-forced deviation inside the reference's own AVX2-vs-generic envelope.
+ * 2 = FAST with the dual fully-connected layer of the sampler in fp16 (weights and GRU-B state as halves, fp32 accumulation,
+ * v_dot2_f32_f16): BASELINE.json config 4's "fp16 dual-FC".  The reference has no fp16 arithmetic to pin it to, so it is
+ * validated against FAST itself: the share of samples whose tree decision changes under teacher forcing
+ * (tests/test_gpu_fast.py::test_fp16_dual_fc_decision_flips). */
 LPCNET_EXPORT int lpcnet_batch_set_fast(LPCNetBatch *b, int on);
 LPCNET_EXPORT int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets,
                                              void *hip_stream);

@@ -327,8 +327,8 @@ class LPCNetBatch:
     def set_end2end(self, on: bool = True):
         self._chk(self.L.lpcnet_batch_set_end2end(self.p, int(on)), "set_end2end")
 
-    def set_fast(self, on: bool = True):
-        """FAST arithmetic (FMA / int32 accumulation); default is PARITY (bit-exact)"""
+    def set_fast(self, on=True):
+        """FAST arithmetic (FMA / int32 accumulation); default is PARITY (bit-exact).  on = 2: FAST with the dual FC in fp16."""
         self._chk(self.L.lpcnet_batch_set_fast(self.p, int(on)), "set_fast")
 
     def decode_device(self, d_packets_ptr: int, d_pcm_ptr: int, n_packets: int, hip_stream: int = 0):

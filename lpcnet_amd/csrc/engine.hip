@@ -38,6 +38,7 @@ struct lpcn_engine {
     int device = 0;
     int nw = 0, nw_variant = 0, nb_b = 0;
     bool is_int8 = false;
+    bool fc_f16 = false;               // FAST sub-option: fp16 dual FC (lpcn_engine_set_fast(e, 2))
     bool fast = false;                 // FAST arithmetic (lpcn_engine_set_fast): fused / integer accumulation instead of the reference's generic-C order
     float lpc_gamma = 1.f;
     hipStream_t stream = nullptr;
@@ -196,6 +197,16 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     UP(float, fc_w, m->fc_w, 256 * 2 * LPCN_N_B);
     UP(float, fc_b, m->fc_b, 512);
     UP(float, fc_f, m->fc_f, 512);
+    {   // fp16 image of the dual-FC weights, packed in pairs (FAST sub-option)
+        std::vector<uint32_t> wh(256 * 2 * LPCN_N_B / 2);
+        for (size_t i = 0; i < wh.size(); ++i) {
+            const _Float16 lo = (_Float16)m->fc_w[2 * i], hi = (_Float16)m->fc_w[2 * i + 1];
+            uint16_t l, h;
+            memcpy(&l, &lo, 2); memcpy(&h, &hi, 2);
+            wh[i] = (uint32_t)l | ((uint32_t)h << 16);
+        }
+        UP(uint32_t, fc_wh, wh.data(), wh.size());
+    }
     UP(float, tab_tansig, lpcn_tansig, 201);
     UP(float, tab_ulaw2lin, lpcn_ulaw2lin_tab, 256);
     UP(float, tab_logit, lpcn_logit_tab, 256);
@@ -279,6 +290,7 @@ extern "C" int lpcn_engine_set_end2end(lpcn_engine *e, int on)
 extern "C" int lpcn_engine_set_fast(lpcn_engine *e, int on)
 {
     e->fast = on != 0;
+    e->fc_f16 = on == 2;              // 2 = FAST with the dual FC in fp16 (BASELINE config 4's wording; weights converted at engine creation)
     return 0;
 }
 extern "C" int lpcn_engine_set_lpc_gamma(lpcn_engine *e, float gamma)
@@ -471,6 +483,7 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.fc_base = fc_from_frames ? b->d_fc_base : nullptr;
     a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
     a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
+    a.fc_f16 = (b->e->fast && b->e->fc_f16) ? 1 : 0;
     a.hmir = getenv("LPCNET_HIP_NO_SCALAR_GRUB") ? nullptr : b->d_hmir;      // (tools: the LDS + DPP form of GRU-B for comparison)
     HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
     const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0;

@@ -58,6 +58,8 @@ struct LpcnSampleArgs {
     const float *b_rec;                             // [16][48] fp32, or [48 rows][4] dwords of 4 int8
     const float *b_bias;                            // [2][48]
     const float *fc_w, *fc_b, *fc_f;                // [256][2][16], [2][256], [2][256]
+    const uint32_t *fc_wh;                          // FAST sub-option: dual-FC weights as fp16 pairs [256][2][8] (BASELINE config 4: "fp16 dual-FC")
+    int fc_f16;                                     // non-zero: the tree phase runs on fc_wh with v_dot2_f32_f16 (FAST only)
     const float *tab_tansig, *tab_ulaw2lin, *tab_logit;
     int nb_b;
     int b_dense;                                    // GRU-B lists all 96 input blocks for every row group, in order
@@ -79,7 +81,7 @@ struct LpcnSampleArgs {
 #ifndef LPCN_ENABLE_PROF
 #define LPCN_ENABLE_PROF 0
 #endif
-#define LPCN_DBG_STRIDE 1600    // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,pred, leader clocks barrier->publish; [448..1600) GRU-A pre-activations
+#define LPCN_DBG_STRIDE 1600    // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,pred, leader clocks barrier->publish, the tree's own decision; [448..1600) GRU-A pre-activations
 
 namespace lpcn {
 
@@ -120,7 +122,8 @@ template <int S> struct Lds {
     static constexpr int condb  = flag + 16;                        // [S][48] f32
     static constexpr int lpc    = condb + S * RB * 4;               // [S][16] f32
     static constexpr int sig    = lpc + S * 64;                     // [S][16] f32 ring of past samples
-    static constexpr int pcmbuf = sig + S * 64;                     // [S][160] i16
+    static constexpr int hBh    = sig + S * 64;                     // [S][16] f16: GRU-B state as halves (FAST fp16 dual-FC)
+    static constexpr int pcmbuf = hBh + S * 32;                     // [S][160] i16
     static constexpr int tansig = pcmbuf + S * 320;                 // [204] f32
     static constexpr int ulaw   = tansig + 816;                     // [256] f32 mu-law decode table
     static constexpr int logit  = ulaw + 1024;                      // [256] f32 sampling thresholds
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             const float hv0 = states[stream_of(i / NB)].gru_b[i % NB];
             sm_hB[i] = hv0;
             if constexpr (I8) smem[L::hBq + i] = (unsigned char)quant_s8(hv0);
+            if constexpr (FAST) ((_Float16 *)(smem + L::hBh))[i] = (_Float16)hv0;
         }
         // leader-lane state (lane s of wave 0 leads stream s); kept in LDS between samples
         if (tid < S) {
@@ -990,8 +994,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             const int node = tid >> 1, chan = tid & 1;
             const auto *fcw_ptr = as_global(Ap->fc_w) + node * 2 * NB + chan * NB;
             float fcw[NB];
+            bool fc_f16 = false;
+            if constexpr (FAST) fc_f16 = Ap->fc_f16 != 0;
+            if (FAST && fc_f16) {                            // 8 dwords of fp16 pairs instead of 16 floats
+                const auto *wh = as_global(Ap->fc_wh) + (node * 2 + chan) * (NB / 2);
+#pragma unroll
+                for (int j = 0; j < NB / 2; ++j) fcw[j] = __builtin_bit_cast(float, wh[j]);
+#pragma unroll
+                for (int j = NB / 2; j < NB; ++j) fcw[j] = 0.f;
+            } else {
 #pragma unroll
             for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
+            }
             const float fcb = as_global(Ap->fc_b)[chan * 256 + node], fcf = as_global(Ap->fc_f)[chan * 256 + node];
             LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
@@ -1294,6 +1308,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     if ((live_mask >> s) & 1) {
                         sm_hB[s * NB + lane] = hnew;
                         if constexpr (I8) smem[L::hBq + s * NB + lane] = (unsigned char)quant_s8(hnew);
+                        if constexpr (FAST) ((_Float16 *)(smem + L::hBh))[s * NB + lane] = (_Float16)hnew;
                     }
                 }
             }
@@ -1314,10 +1329,20 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     float sum = fcb;
+                    if (FAST && fc_f16) {
+                        // fp16 dual FC (FAST sub-option): weights and GRU-B state as halves, fp32 accumulation, two MACs per
+                        // v_dot2_f32_f16 -- half the instructions and half the operand bytes of the tree phase
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        const uint32_t *hh = (const uint32_t *)(smem + L::hBh + s * 32);
+#pragma unroll
+                        for (int j = 0; j < NB / 2; ++j)
+                            sum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, fcw[j]), __builtin_bit_cast(h2, hh[j]), sum, false);
+                    } else {
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {                                          // src/nnet.c:194-199
                         if constexpr (FAST) sum = __builtin_fmaf(fcw[j], sm_hB[s * NB + j], sum);
                         else sum = sum + fcw[j] * sm_hB[s * NB + j];
+                    }
                     }
                     const float v = fcf * act_tanh<FAST>(sum, sm_tansig);
                     // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
@@ -1345,6 +1370,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (more) ++seq;
             unsigned long long t_b4 = 0;
             if (Ap->dbg) t_b4 = __builtin_amdgcn_s_memtime();                 // tests: leader latency barrier -> publish
+#ifndef LPCN_LEADER_PRIO
+#define LPCN_LEADER_PRIO 3
+#endif
+            // the leader's dependent chain is what every other wave waits for: it wins issue arbitration against the wave that
+            // shares its SIMD (which is already running next sample's candidate items at priority 2) until the indices are out
+            if (tid < 64 && LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(LPCN_LEADER_PRIO);
             if (tid < 16 * S) {
                 const int lrow = (tid & 63) >> 4, tap = tid & 15;
                 float pcm = 0.f, deemph = 0.f;
@@ -1376,6 +1407,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         val = (val << 1) | bit_of((k & 4) ? b1 : b0, val & 15);
                     }
                     exc = val;
+                    if (Ap->dbg && tid == 0 && blockIdx.x == 0)                  // tests: the tree's own decision (teacher forcing overrides exc below)
+                        Ap->dbg[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 406] = (float)val;
                     if (smp < preload) {                                        // src/lpcnet.c:256-258
                         const float x = (float)sm_pcm[lrow * LPCN_FRAME_SIZE + smp];
                         exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
@@ -1395,6 +1428,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 // the next sample's indices first: the other waves are waiting for them
                 if (more) { open_sample(live, pcm, tap == 0 ? pcm * lpc_tap : prod_old, exc, false); publish_indices(); }
+                if (LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(0);
                 if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live)
                     Ap->dbg[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 405] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_b4);
                 if (tap == 0) {

@@ -91,3 +91,56 @@ def test_fast_free_running_is_sane_and_switchable(flavour, hip_lib):
     b.set_fast(False)
     assert np.array_equal(b.synthesize(feats), parity)
     b.close()
+
+
+def _tree_decisions(blob, feats, pcm, fast):
+    """teacher-forced run of ONE stream; the sampler's own decision per sample (the trace keeps it although the forced
+    signal overrides it) and the GRU-B state it was drawn from"""
+    T = feats.shape[1]
+    b = api.LPCNetBatch(1, blob)
+    b.set_fast(fast)
+    b.debug_trace_alloc(T * 160)
+    b.synthesize(feats, preload_pcm=pcm, preload=160)
+    tr = b.debug_trace_fetch(T * 160)
+    b.debug_trace_alloc(0)
+    b.close()
+    return tr[320:, 406].astype(np.int32), tr[320:, 384:400]
+
+
+@pytest.mark.parametrize("flavour", ["float", "int8"])
+def test_fp16_dual_fc_decision_flips(flavour, hip_lib):
+    """BASELINE.json config 4 names an fp16 dual FC.  It is a FAST sub-option (lpcnet_batch_set_fast(b, 2)); the reference
+    has nothing to pin it to, so it is measured against FAST with the fp32 tree, teacher-forced on the same signal (same
+    GRU-B states up to FAST's own last-bit effects, same thresholds): the tree decision may change only where a logit
+    sits within fp16 rounding of its threshold.  For scale, the share of decisions FAST itself changes against PARITY is
+    measured the same way."""
+    blob = synth.blob_bytes(synth.make_model(flavour=flavour))
+    T = 60
+    feats = synth.make_features(9100, T)[None]
+    ref = api.LPCNetBatch(1, blob)
+    pcm = ref.synthesize(feats)
+    ref.close()
+    d_par, hb_par = _tree_decisions(blob, feats, pcm, 0)
+    d_fast, hb_fast = _tree_decisions(blob, feats, pcm, 1)
+    d_f16, hb_f16 = _tree_decisions(blob, feats, pcm, 2)
+    n = d_par.size
+    assert n == (T - 2) * 160 and np.unique(d_par).size > 20           # a live sampler, not a stuck one
+    assert np.array_equal(hb_fast, hb_f16)                               # the fp16 tree changes nothing upstream of the tree
+    flips_fast = float((d_fast != d_par).mean())
+    flips_f16 = float((d_f16 != d_fast).mean())
+    # fp16 weights and state perturb a logit by ~1e-3 of its range: a few per cent of the decisions sit that close to a threshold
+    assert flips_f16 < 0.06, (flips_f16, flips_fast)
+    # and a changed decision is a NEIGHBOURING one far more often than not (the low bits of the mu-law code)
+    moved = np.abs(d_f16 - d_fast)[d_f16 != d_fast]
+    assert moved.size == 0 or np.median(moved) <= 8, (np.median(moved), moved[:20])
+    print("decision flips: FAST vs PARITY %.4f, fp16 tree vs FAST %.4f (%d samples)" % (flips_fast, flips_f16, n))
+    # free running: sane statistics
+    b = api.LPCNetBatch(4, blob)
+    b.set_fast(2)
+    f4 = np.stack([synth.make_features(9200 + s, 30) for s in range(4)])
+    out = b.synthesize(f4)
+    b.set_fast(0); b.reset()
+    par = b.synthesize(f4)
+    b.close()
+    r = out[:, 320:].astype(np.float64).std() / par[:, 320:].astype(np.float64).std()
+    assert np.all(out[:, :320] == 0) and 0.7 < r < 1.4, r
