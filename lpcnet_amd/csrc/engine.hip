@@ -507,15 +507,18 @@ static int launch_frames(lpcn_batch_dev *b, hipStream_t st, const float *d_feat,
 
 // Streams per workgroup, measured instead of looked up (the table in auto_streams_per_wg holds THIS model's step
 // times; a denser / sparser blob or another item-count variant has other optima).  Before the first run of a batch whose
-// value is not pinned, each candidate S runs two live frames (one to warm up, one timed with HIP events) on the batch's own
-// buffers -- zeroed frame products, the stream states saved and restored around it -- and the fastest wins.  ~6 launches of
-// a few ms, once per batch and arithmetic flavour; LPCNET_HIP_NO_AUTOTUNE=1 keeps the table value.
+// value is not pinned, each candidate S runs live frames on the batch's own buffers -- zeroed frame products, the stream
+// states saved and restored around it -- timed with HIP events: a warm-up launch, then one frame and five frames; the
+// DIFFERENCE is the steady-state cost of four frames (a launch's prologue -- filling registers and LDS with the weights --
+// is ~4 % of a two-frame launch and grows with the workgroup count, which biased a plain two-frame timing against the
+// two-workgroups-per-CU form of the int8 kernel).  ~9 launches, ~12 ms, once per batch and arithmetic flavour;
+// LPCNET_HIP_NO_AUTOTUNE=1 keeps the table value.
 static int autotune_streams_per_wg(lpcn_batch_dev *b, hipStream_t st)
 {
     b->tuned = true;
     const char *off = getenv("LPCNET_HIP_NO_AUTOTUNE");
     if ((off && *off == '1') || b->n < 2) return 0;           // (one stream: one workgroup whatever S is)
-    const int nf = 2 < b->max_chunk ? 2 : b->max_chunk;
+    const int nf = 5 < b->max_chunk ? 5 : b->max_chunk;
     int rc = 0;
     lpcn_stream_state *saved = nullptr;
     short *pcm = nullptr;                                    // (a buffer of its own: the caller may be holding the staging buffer's address)
@@ -535,14 +538,18 @@ static int autotune_streams_per_wg(lpcn_batch_dev *b, hipStream_t st)
     float best_ms = -1.f;
     for (int S = 1; S <= 4; S *= 2) {
         b->S = S; b->pack2 = use_pack2(b->e, b->n, S);
-        float ms = 0.f;
-        for (int pass = 0; pass < 2 && !rc; ++pass) {
+        float ms = 0.f, ms1 = 0.f;
+        for (int pass = 0; pass < 3 && !rc; ++pass) {          // warm-up (1 frame), 1 frame, nf frames
+            const int k = pass == 2 ? nf : 1;
+            float t = 0.f;
             if (hipEventRecord(b->ev[1], st) != hipSuccess) rc = LPCN_E_HIP;
-            if (!rc) rc = launch_sample(b, st, pcm, (size_t)nf * LPCN_FRAME_SIZE, nf, 0, true);
+            if (!rc) rc = launch_sample(b, st, pcm, (size_t)nf * LPCN_FRAME_SIZE, k, 0, true);
             if (!rc && (hipEventRecord(b->ev[2], st) != hipSuccess || hipEventSynchronize(b->ev[2]) != hipSuccess ||
-                        hipEventElapsedTime(&ms, b->ev[1], b->ev[2]) != hipSuccess)) rc = LPCN_E_HIP;
+                        hipEventElapsedTime(&t, b->ev[1], b->ev[2]) != hipSuccess)) rc = LPCN_E_HIP;
+            if (pass == 1) ms1 = t; else ms = t;
         }
         if (rc) break;
+        if (nf > 1) ms -= ms1;                                  // nf - 1 frames in steady state
         if (best_ms < 0.f || ms < best_ms) { best_ms = ms; best = S; }
     }
     // the measurement ran on the real state: put it back

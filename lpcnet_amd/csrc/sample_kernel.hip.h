@@ -20,8 +20,13 @@
 //     ds_read_b128 per item) and the other three streams arrive through DPP quad_perm
 //     broadcasts folded into the multiplies -- LDS traffic is 1/S of the naive scheme.
 //     int8 blobs: the state is quantised once per sample; v_dot4_i32_i8 per (item, stream).
-//   * GRU-B input weights (<=73.7 KB) + recurrent matrix live in LDS; one wave per stream, one
-//     lane per output row, gates exchanged with wave shuffles (no barrier).
+//   * GRU-B input weights (<=73.7 KB) + recurrent matrix live in LDS; one wave per stream, one lane per output row, gates
+//     exchanged with wave shuffles (no barrier).  Its state operand -- the same 384 values for every row -- does NOT come
+//     from LDS: the gate stage mirrors the new GRU-A state into an L2-resident buffer and the stream's GRU-B wave pulls it
+//     through the scalar cache into SGPRs (s_load_dwordx16 = 4 blocks), used as SGPR-pair operands of v_pk_mul_f32.  The
+//     whole 96-block loop is one hand-scheduled assembly block (grub_scalar_loop.inc, tools/gen_grub_asm.py): a scalar
+//     load must never be in flight across an inline-asm boundary.  (Float blobs with a dense GRU-B input matrix; int8
+//     blobs and block-sparse matrices keep the state in LDS.)
 //   * dual-FC tree: all 255 nodes x 2 channels are evaluated in parallel (lane = node,channel;
 //     18 weight VGPRs), a ballot per wave yields the 255 decision bits.  Speculative evaluation
 //     is exact: every node's logit is a pure function of the GRU-B state.
@@ -30,10 +35,16 @@
 //     Wave 1 draws the KISS99 thresholds of the next sample.
 //
 // Schedule of one sample (4 workgroup barriers B1..B4):
-//   P1 GRU-A rows | B1 | P2 gates | B2 | P3 GRU-B (waves < S)  ||  next sample's candidate-only
-//   slot on waves 4..7 | B3 | P4 tree | B4 | leader publishes the next sample's mu-law indices
-//   through an LDS flag -- no barrier: the other waves are already in P1, running what needs
-//   neither the indices nor the gathered embedding rows, then poll the flag and gather.
+//   P1 GRU-A rows | B1 | P2 gates (+ state mirror stores) | B2 | P3 GRU-B (waves < S)  ||  the HEAD of the next sample's
+//   candidate chains on waves 4..7 | B3 | P4 tree | B4 | leader publishes the next sample's mu-law indices through an LDS
+//   flag -- no barrier: the other waves are already in P1, running what needs neither the indices nor the gathered
+//   embedding rows (the TAIL of their candidate chains), then poll the flag and gather.
+//   A candidate row's sum is sequential, but it need not be formed in one go: model_pack.c stores the first `head` blocks of
+//   every row of a wave's candidate slot end-aligned in the item array; waves 4..7 run them one sample ahead in GRU-B's
+//   shadow, park the partial sums in LDS, and the slot continues from there in P1.
+//   The mirror stores of P2 are not waited for at B2: every wave bumps an LDS arrival counter once its stores are
+//   acknowledged by L2, and a GRU-B wave starts its scalar loads when all eight have arrived (it forms the recurrent part
+//   meanwhile).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -58,8 +69,6 @@ struct LpcnSampleArgs {
     const float *b_rec;                             // [16][48] fp32, or [48 rows][4] dwords of 4 int8
     const float *b_bias;                            // [2][48]
     const float *fc_w, *fc_b, *fc_f;                // [256][2][16], [2][256], [2][256]
-    const uint32_t *fc_wh;                          // FAST sub-option: dual-FC weights as fp16 pairs [256][2][8] (BASELINE config 4: "fp16 dual-FC")
-    int fc_f16;                                     // non-zero: the tree phase runs on fc_wh with v_dot2_f32_f16 (FAST only)
     const float *tab_tansig, *tab_ulaw2lin, *tab_logit;
     int nb_b;
     int b_dense;                                    // GRU-B lists all 96 input blocks for every row group, in order
@@ -76,6 +85,8 @@ struct LpcnSampleArgs {
     float *hmir;                                    // [n_streams + 4][384] L2-resident mirror of the GRU-A state for GRU-B's scalar loads (or NULL)
     float *dbg;                                     // optional per-sample trace (tests)
     unsigned long long *prof;                       // optional: [8] shader-clock totals per phase, workgroup 0 wave 0
+    const uint32_t *fc_wh;                          // FAST sub-option: dual-FC weights as fp16 pairs [256][2][8] (BASELINE config 4: "fp16 dual-FC")
+    int fc_f16;                                     // non-zero: the tree phase runs on fc_wh with v_dot2_f32_f16 (FAST only)
 };
 
 #ifndef LPCN_ENABLE_PROF
@@ -122,8 +133,7 @@ template <int S> struct Lds {
     static constexpr int condb  = flag + 16;                        // [S][48] f32
     static constexpr int lpc    = condb + S * RB * 4;               // [S][16] f32
     static constexpr int sig    = lpc + S * 64;                     // [S][16] f32 ring of past samples
-    static constexpr int hBh    = sig + S * 64;                     // [S][16] f16: GRU-B state as halves (FAST fp16 dual-FC)
-    static constexpr int pcmbuf = hBh + S * 32;                     // [S][160] i16
+    static constexpr int pcmbuf = sig + S * 64;                     // [S][160] i16
     static constexpr int tansig = pcmbuf + S * 320;                 // [204] f32
     static constexpr int ulaw   = tansig + 816;                     // [256] f32 mu-law decode table
     static constexpr int logit  = ulaw + 1024;                      // [256] f32 sampling thresholds
@@ -133,7 +143,8 @@ template <int S> struct Lds {
     static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
     static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
-    static constexpr int total(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 16 : 8)) * (i8 ? 32 : 128); }   // pad: the GRU-B pipeline reads ahead
+    static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 16 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
+    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }                          // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
     static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
     static constexpr int xqT    = hA + 384 * S;                     // [S][96] dwords: the same, stream-major (GRU-B input)
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             const float hv0 = states[stream_of(i / NB)].gru_b[i % NB];
             sm_hB[i] = hv0;
             if constexpr (I8) smem[L::hBq + i] = (unsigned char)quant_s8(hv0);
-            if constexpr (FAST) ((_Float16 *)(smem + L::hBh))[i] = (_Float16)hv0;
+            if constexpr (FAST) ((_Float16 *)(smem + L::hBh(Ap->nb_b, I8)))[i] = (_Float16)hv0;
         }
         // leader-lane state (lane s of wave 0 leads stream s); kept in LDS between samples
         if (tid < S) {
@@ -995,16 +1006,21 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             const auto *fcw_ptr = as_global(Ap->fc_w) + node * 2 * NB + chan * NB;
             float fcw[NB];
             bool fc_f16 = false;
-            if constexpr (FAST) fc_f16 = Ap->fc_f16 != 0;
-            if (FAST && fc_f16) {                            // 8 dwords of fp16 pairs instead of 16 floats
-                const auto *wh = as_global(Ap->fc_wh) + (node * 2 + chan) * (NB / 2);
+            if constexpr (FAST) {
+                fc_f16 = Ap->fc_f16 != 0;
+                if (fc_f16) {                                // 8 dwords of fp16 pairs instead of 16 floats
+                    const auto *wh = as_global(Ap->fc_wh) + (node * 2 + chan) * (NB / 2);
 #pragma unroll
-                for (int j = 0; j < NB / 2; ++j) fcw[j] = __builtin_bit_cast(float, wh[j]);
+                    for (int j = 0; j < NB / 2; ++j) fcw[j] = __builtin_bit_cast(float, wh[j]);
 #pragma unroll
-                for (int j = NB / 2; j < NB; ++j) fcw[j] = 0.f;
+                    for (int j = NB / 2; j < NB; ++j) fcw[j] = 0.f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
+                }
             } else {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
+                for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
             }
             const float fcb = as_global(Ap->fc_b)[chan * 256 + node], fcf = as_global(Ap->fc_f)[chan * 256 + node];
             LPCN_PROF(7);      // dual-FC prefetch issue
@@ -1308,7 +1324,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     if ((live_mask >> s) & 1) {
                         sm_hB[s * NB + lane] = hnew;
                         if constexpr (I8) smem[L::hBq + s * NB + lane] = (unsigned char)quant_s8(hnew);
-                        if constexpr (FAST) ((_Float16 *)(smem + L::hBh))[s * NB + lane] = (_Float16)hnew;
+                        if constexpr (FAST) ((_Float16 *)(smem + L::hBh(Ap->nb_b, I8)))[s * NB + lane] = (_Float16)hnew;
                     }
                 }
             }
@@ -1329,20 +1345,22 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     float sum = fcb;
-                    if (FAST && fc_f16) {
-                        // fp16 dual FC (FAST sub-option): weights and GRU-B state as halves, fp32 accumulation, two MACs per
-                        // v_dot2_f32_f16 -- half the instructions and half the operand bytes of the tree phase
-                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                        const uint32_t *hh = (const uint32_t *)(smem + L::hBh + s * 32);
+                    if constexpr (FAST) {
+                        if (fc_f16) {
+                            // fp16 dual FC (FAST sub-option): weights and GRU-B state as halves, fp32 accumulation, two MACs per
+                            // v_dot2_f32_f16 -- half the instructions and half the operand bytes of the tree phase
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                            const uint32_t *hh = (const uint32_t *)(smem + L::hBh(Ap->nb_b, I8) + s * 32);
 #pragma unroll
-                        for (int j = 0; j < NB / 2; ++j)
-                            sum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, fcw[j]), __builtin_bit_cast(h2, hh[j]), sum, false);
+                            for (int j = 0; j < NB / 2; ++j)
+                                sum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, fcw[j]), __builtin_bit_cast(h2, hh[j]), sum, false);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) sum = __builtin_fmaf(fcw[j], sm_hB[s * NB + j], sum);
+                        }
                     } else {
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) {                                          // src/nnet.c:194-199
-                        if constexpr (FAST) sum = __builtin_fmaf(fcw[j], sm_hB[s * NB + j], sum);
-                        else sum = sum + fcw[j] * sm_hB[s * NB + j];
-                    }
+                        for (int j = 0; j < NB; ++j) sum = sum + fcw[j] * sm_hB[s * NB + j];                   // src/nnet.c:194-199
                     }
                     const float v = fcf * act_tanh<FAST>(sum, sm_tansig);
                     // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
@@ -1378,16 +1396,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (tid < 64 && LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(LPCN_LEADER_PRIO);
             if (tid < 16 * S) {
                 const int lrow = (tid & 63) >> 4, tap = tid & 15;
-                float pcm = 0.f, deemph = 0.f;
-                int exc = 0;
-                if (live) {                                  // (all 16 lanes of a stream's row do the same walk)
-                    // the stream's 255 decision bits = 16 dwords: node i was evaluated by wave i>>5 and sits at ballot bit
-                    // 2*(i&31), i.e. dword i>>4, bit 2*(i&15).  (32-bit selects and bit-field extracts: no 64-bit shifts.)
+                auto walk_tree = [&](int lrow) {             // the sampler's 8 decisions from the 255 ballot bits of stream row lrow
                     typedef unsigned u4 __attribute__((ext_vector_type(4)));
                     const u4 *mk = (const u4 *)(sm_mask + lrow * 8);
                     const u4 qa = mk[0], qb = mk[1], qc = mk[2], qd = mk[3];
-                    const float pred = sm_lead[lrow * 8 + 0];           // (issued together with the mask reads)
-                    deemph = sm_lead[lrow * 8 + 1];
                     auto bit_of = [](unsigned word, int k) { return (int)((word >> (2 * k)) & 1u); };
                     int val = 0;
 #pragma unroll
@@ -1406,9 +1418,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         const unsigned b0 = (k & 2) ? a1 : a0, b1 = (k & 2) ? a3 : a2;
                         val = (val << 1) | bit_of((k & 4) ? b1 : b0, val & 15);
                     }
+                    return val;
+                };
+                float pcm = 0.f, deemph = 0.f;
+                int exc = 0;                   // (tree_val: the tree's own decision -- teacher forcing overrides exc)
+                if (live) {                                  // (all 16 lanes of a stream's row do the same walk)
+                    const float pred = sm_lead[lrow * 8 + 0];           // (issued together with the mask reads)
+                    deemph = sm_lead[lrow * 8 + 1];
+                    const int val = walk_tree(lrow);
                     exc = val;
-                    if (Ap->dbg && tid == 0 && blockIdx.x == 0)                  // tests: the tree's own decision (teacher forcing overrides exc below)
-                        Ap->dbg[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 406] = (float)val;
                     if (smp < preload) {                                        // src/lpcnet.c:256-258
                         const float x = (float)sm_pcm[lrow * LPCN_FRAME_SIZE + smp];
                         exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
@@ -1436,6 +1454,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
                             float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
                             d[0] = (float)exc; d[3] = pcm + 0.85f * deemph; d[4] = pcm - sm_ulaw[exc];
+                            // the tree's own decision (teacher forcing overrides exc) is walked AGAIN here, in the cold trace branch:
+                            // any use of the leader's value this far down (a register, an extra LDS store) cost 17 spilled
+                            // SGPRs in the sample loop and 2.3 % of the float kernel
+                            asm volatile("" ::: "memory");
+                            d[6] = (float)walk_tree(lrow);
                         }
                         pcm = pcm + 0.85f * deemph;
                         sm_lead[lrow * 8 + 1] = pcm;                            // de-emphasis memory

@@ -25,6 +25,8 @@ T = {0: 36, 1: 52}     # SGPR tuple base per buffer
 W = {0: 216, 1: 232}   # VGPR weight base per buffer (4 blocks x float4)
 P = {0: 248, 1: 252}   # product registers (alternate per block)
 OFF, OFFC, CNT, DUMMY = 68, 69, 70, 71
+import sys
+PHASE = int(sys.argv[sys.argv.index("--phase") + 1]) if "--phase" in sys.argv else 0
 
 
 def pk_mul(dst, sreg, vreg):
@@ -89,6 +91,11 @@ def main():
     lines += [f"ds_read_b128 v[{W[0] + 4 * j}:{W[0] + 4 * j + 3}], %[wp] offset:{128 * j}" for j in range(4)]
     lines += [f"ds_read_b128 v[{W[1] + 4 * j}:{W[1] + 4 * j + 3}], %[wp] offset:{512 + 128 * j}" for j in range(4)]
     lines += ["s_waitcnt lgkmcnt(0)"] + products(0, 0, 0)
+    # Code placement: a hand-written stream is sensitive to where its loop body starts modulo 8 bytes (MI355X_MICROARCH.md,
+    # "Code-placement sensitivity": a byte-identical stream lost 13 % under a 4-mod-8 shift; here an unrelated edit that moved
+    # the block by 4 bytes cost the whole kernel 3.5 %).  The loop head is therefore pinned to a 16-byte boundary
+    # (+ PHASE x 4 bytes, chosen by measurement: see LPCN_GRUB_PHASE in sample_kernel.hip.h).
+    lines += [".p2align 4"] + ["s_nop 0"] * PHASE
     lines += ["1:"]
     for k in range(GROUPS_PER_TRIP):
         lines += group(k, k & 1, (k + 2) * 512)

@@ -1,17 +1,24 @@
 #!/bin/bash
 # Collect the round's measurement evidence on a GPU box (run through gpurun from the repo root):
-#   bench JSON lines (fp32 + int8), rocprofv3 kernel stats, HBM traffic from PMC counters (separate passes).
-# Everything lands in gpurun_out/prof/; tools/profile_summarize.py turns it into profiles/.
+#   bench JSON lines (fp32 + int8, PARITY + FAST, single stream, multi-rank rehearsal), rocprofv3 kernel stats, HBM traffic from
+#   PMC counters (separate passes), SQ / LDS counters, in-kernel phase clocks, the reference demo's real-time factors.
+# Everything lands in gpurun_out/prof/; tools/profile_summarize.py <round> turns it into profiles/<round>_*.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
+RND=${1:-r03}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 timeout 300 python bench.py --int8 > $OUT/bench_i8.json 2> $OUT/bench_i8.err
 timeout 300 python bench.py --streams 1 --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err      # BASELINE config 1
 timeout 300 python bench.py --fast --no-cpu-baseline > $OUT/bench_f32_fast.json 2> $OUT/bench_f32_fast.err
+timeout 300 python bench.py --fast --fp16-fc --no-cpu-baseline > $OUT/bench_f32_fast_f16.json 2> $OUT/bench_f32_fast_f16.err
 timeout 300 python bench.py --int8 --fast --spw 2 --no-cpu-baseline > $OUT/bench_i8_fast.json 2> $OUT/bench_i8_fast.err
+timeout 300 python bench.py --int8 --fast --fp16-fc --spw 2 --no-cpu-baseline > $OUT/bench_i8_fast_f16.json 2> $OUT/bench_i8_fast_f16.err   # BASELINE config 4 as worded
+timeout 600 python bench.py --gpus 2 --share-device --no-cpu-baseline > $OUT/bench_rehearsal_2ranks.json 2> $OUT/bench_rehearsal_2ranks.err
+# the GRU-B form of round 2 (state from LDS + DPP) on this round's kernel, for the A/B line in DESIGN.md
+LPCNET_HIP_NO_SCALAR_GRUB=1 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_f32_lds_state_grub.json 2> /dev/null
 # BASELINE configs 0 -> 1: the reference's own demo on the engine vs its AVX2 builds, one 10-s feature file (wall seconds incl. process start)
 python tools/rtf_demo.py > $OUT/rtf_demo.json 2> $OUT/rtf_demo.err
 for fl in f32 i8; do
@@ -20,11 +27,12 @@ for fl in f32 i8; do
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
 done
-python tools/profile_sq.py --tag r02 > $OUT/sq_f32.log 2>&1
-python tools/profile_sq.py --int8 --tag r02 > $OUT/sq_i8.log 2>&1
-# in-kernel s_memtime phase tables (profiling build of the library: python -m lpcnet_amd.build --prof)
+python tools/profile_sq.py --tag $RND > $OUT/sq_f32.log 2>&1
+python tools/profile_sq.py --int8 --tag $RND > $OUT/sq_i8.log 2>&1
+# in-kernel s_memtime phase tables (profiling build of the library: LPCN_PROF_MASK=0xFFF python -m lpcnet_amd.build --prof)
 if [ -f lpcnet_amd/liblpcnet_hip_prof.so ]; then
-  LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32.log 2>&1
+  LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1:1 > $OUT/phase_f32.log 2>&1
+  LPCNET_HIP_NO_SCALAR_GRUB=1 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32_lds_state_grub.log 2>&1
   LPCN_FLAVOUR=int8 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1024:2 > $OUT/phase_i8.log 2>&1
 fi
 find $OUT -name "*.csv" | head -40

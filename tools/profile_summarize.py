@@ -47,7 +47,9 @@ for fl, suffix in (("f32", ""), ("i8", "_int8")):
                        "command": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace)"},
                       open(os.path.join(DST, f"{RND}_hbm_traffic{suffix}.json"), "w"), indent=1)
 for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_fast.json", "bench_n1_fast.json"),
-                 ("bench_i8_fast.json", "bench_n1_int8_fast.json"), ("rtf_demo.json", "demo_single_stream_rtf.json")):
+                 ("bench_i8_fast.json", "bench_n1_int8_fast.json"), ("rtf_demo.json", "demo_single_stream_rtf.json"),
+                 ("bench_f32_fast_f16.json", "bench_n1_fast_fp16fc.json"), ("bench_i8_fast_f16.json", "bench_n1_int8_fast_fp16fc.json"),
+                 ("bench_rehearsal_2ranks.json", "bench_rehearsal_2ranks_one_gpu.json"), ("bench_f32_lds_state_grub.json", "bench_n1_lds_state_grub.json")):
     b = os.path.join(SRC, src)
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(DST, f"{RND}_{dst}"))
@@ -55,11 +57,16 @@ for fl, suffix in (("f32", ""), ("i8", "_int8")):
     b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
     if os.path.exists(b):
         shutil.copy(b, os.path.join(DST, f"{RND}_sq_counters{suffix}.csv"))
-ph = [os.path.join(SRC, f) for f in ("phase_f32.log", "phase_i8.log") if os.path.exists(os.path.join(SRC, f))]
+ph = [os.path.join(SRC, f) for f in ("phase_f32.log", "phase_f32_lds_state_grub.log", "phase_i8.log") if os.path.exists(os.path.join(SRC, f))]
 if ph:
     with open(os.path.join(DST, f"{RND}_phase_clocks.txt"), "w") as o:
-        o.write("# in-kernel s_memtime phase table (profiling build: python -m lpcnet_amd.build --prof; LPCNET_HIP_LIB=.../liblpcnet_hip_prof.so\n"
-                "# python tests/tools/gpu_sweep.py 22 1024:4), shader clocks per sample step, workgroup 0; the instrumentation itself costs a few %\n")
+        o.write("# in-kernel s_memtime phase table (profiling build: LPCN_PROF_MASK=0xFFF python -m lpcnet_amd.build --prof; LPCNET_HIP_LIB=.../liblpcnet_hip_prof.so\n"
+                "# python tests/tools/gpu_sweep.py 22 1024:4), shader clocks per sample step, workgroup 0; the instrumentation itself costs a few %\n"
+                "# columns: B1wait = wait at the barrier behind GRU-A; P2 = GRU-A gates; P3tail = wait at the barrier behind GRU-B; P4 = tree; P5 = leader /\n"
+                "# thresholds; gather, close = GRU-A begin / end work; fcpre = dual-FC prefetch (+ mirror arrival); gruB = GRU-B mat-vec (incl. recurrent part,\n"
+                "# arrival wait, scalar-cache warm-up); items = GRU-A item chain; start = wait for the indices + gather + start values; P5a = GRU-B gates\n"
+                "# (waves 0..3) / early candidate heads (waves 4..7)\n")
         for f in ph:
+            o.write("## " + os.path.basename(f) + "\n")
             o.write(open(f).read())
 print(sorted(os.listdir(DST)))
