@@ -409,7 +409,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         }
         const auto *bw = as_global(Ap->b_w);
         constexpr int BW_DW = I8 ? 8 : 32;                  // dwords per GRU-B block
-        for (int i = tid; i < (nb_b + (I8 ? 16 : 8)) * BW_DW; i += LPCN_WG_THREADS) ((uint32_t *)(smem + L::bw))[i] = i < nb_b * BW_DW ? ((const LPCN_GLOBAL uint32_t *)bw)[i] : 0u;
+        for (int i = tid; i < (nb_b + (I8 ? 16 : 8)) * BW_DW; i += LPCN_WG_THREADS) {
+            int di = i;
+            if constexpr (FAST && !I8 && S >= 2) {
+                // the matrix-pipe GRU-B (dense input matrix) reads 4 rows x 16 consecutive blocks per instruction: [row quad][block][row][4]
+                // makes that one contiguous KB (the common [block][8 rows][4] order costs a two-way bank conflict there)
+                if (b_dense && i < nb_b * BW_DW) {
+                    const int blk_abs = i >> 5, ri = (i >> 2) & 7, c = i & 3;
+                    di = ((((blk_abs / 96) * 2 + (ri >> 2)) * 96 + blk_abs % 96) * 4 + (ri & 3)) * 4 + c;
+                }
+            }
+            ((uint32_t *)(smem + L::bw))[di] = i < nb_b * BW_DW ? ((const LPCN_GLOBAL uint32_t *)bw)[i] : 0u;
+        }
         for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
             const int s = i / NA, n = i % NA;
             const float hv0 = states[stream_of(s)].gru_a[n];
@@ -521,6 +532,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         unsigned long long ex;
         asm volatile("s_waitcnt vmcnt(0)\n\t"
                      "s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %1, %2\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(ex) : "v"(arrive_addr), "v"(one) : "memory");
+    };
+    auto lds_arrive = [&]() {                                 // the same counter for hand-offs through LDS: no store round trip to wait for
+        int one = 1;
+        unsigned long long ex;
+        asm volatile("s_mov_b64 %0, exec\n\t"
                      "s_mov_b64 exec, 1\n\t"
                      "ds_add_u32 %1, %2\n\t"
                      "s_mov_b64 exec, %0"
@@ -868,6 +888,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_REMAT_S(b3);
             // All tests below are wave-uniform scalar branches.  A taken branch costs ~35 clk of refetch, so the
             // common case (an ordinary item) must fall through every one of them: hence the expectations.
+            int nextb = b1;
+            LPCN_REMAT_S(nextb);
             auto item = [&](const int j) -> bool {           // false: this wave has no more items
                 if ((j == 10 || j == 14 || j == 18) && j >= JSTAR_MIN && j <= JSTAR_MAX && __builtin_expect(j == jstar, 0)) {
                     if (jmode) {
@@ -878,11 +900,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 if (__builtin_expect(j >= jend, 0)) return false;
                 if (j + PF < NW) fetch_h(j + PF);
-                // slot boundaries (a slot may be empty: b1 == b2, or b1 == 0)
-                // (the rare blocks drain their own LDS traffic -- s_waitcnt lgkmcnt(0) -- so that the join with the
+                // slot boundaries (a slot may be empty: b1 == b2, or b1 == 0): ONE scalar compare per item against the next one
+                // (the rare block drains its own LDS traffic -- s_waitcnt lgkmcnt(0) -- so that the join with the
                 // common path keeps its precise wait counts)
-                if (__builtin_expect(j == b1, 0)) { row_swap(0, 1); __builtin_amdgcn_s_waitcnt(0xC07F); }
-                if (__builtin_expect(j == b2, 0)) { row_swap(1, 2); __builtin_amdgcn_s_waitcnt(0xC07F); }
+                if (__builtin_expect(j == nextb, 0)) {
+                    if (j == b1) row_swap(0, 1);
+                    if (j == b2) row_swap(1, 2);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    nextb = b1 > j ? b1 : (b2 > j ? b2 : NW);
+                }
                 mac(j);
                 return true;
             };
@@ -939,7 +965,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             __syncthreads();                                                   // B1
             LPCN_PROF(0);
             if (Ap->dbg && blockIdx.x == 0) {                                  // tests: recurrent pre-activations of stream 0
-                float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 448;
+                LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 448;
                 for (int i = tid0; i < RA; i += LPCN_WG_THREADS) d[i] = sm_pre[i * S];
             }
 
@@ -1058,7 +1084,71 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // a row's sum is free in FAST), the parts meet in LDS (sm_inh is idle in this phase).  The helper's early slot
             // (e items of ~80 clk on the matrix pipe) comes first, a quad costs ~290 clk here: both finish together with
             // gb_qa = (24 + e * 0.28) / 2 quads on the stream's own wave.
-            const bool gb_fsplit = FAST && !I8 && b_dense && S <= LPCN_WAVES / 2;
+            // FAST, float blobs, dense input matrix, S >= 2: the input mat-vec of ALL streams of the workgroup is one small GEMM,
+            // [48 rows x 384] x [384 x S], on the matrix pipe.  v_mfma_f32_4x4x1_16B: each of the 16 quads of a wave forms a
+            // (4 rows) x (4 streams) outer product for ITS input column and accumulates it, so one instruction covers 16
+            // columns; a unit = (row quad, half of the 384 columns) = 3 weight reads + 3 state reads (16 bytes per lane, the
+            // state straight out of the layout the other paths use) + 12 MFMAs.  The 24 units are dealt unevenly: the waves
+            // that run a candidate head afterwards take two, the gate waves (which only have the recurrent part and the
+            // gates left) more.  The 16 quads' sums are folded with two DPP row shifts, the remaining 4 rows x 2 halves meet
+            // in LDS (sm_inh is idle in this phase) and the stream's gate wave adds them up.  No workgroup barrier: every wave
+            // bumps the arrival counter behind its LDS stores (LDS operations of a wave complete in order) and goes on; only
+            // the gate waves wait for all eight.  ~2 k clk of GRU-B instead of ~6 k for one FMA chain per stream.
+            const bool gb_mfma = FAST && !I8 && b_dense && S >= 2;
+            if constexpr (FAST && !I8 && S >= 2) {
+                if (b_dense) {                               // (workgroup-uniform)
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    ++gbseq;
+                    // unit n = (column half n / 12, row quad n % 12); a wave's units lie in one half
+                    int n0, n1;
+                    if constexpr (S == 4) { n0 = wave < 4 ? 4 * wave : 8 + 2 * wave; n1 = n0 + (wave < 4 ? 4 : 2); }
+                    else { n0 = wave < 2 ? 2 * wave : (wave == 2 ? 4 : (wave == 3 ? 12 : 8 + 2 * wave)); n1 = n0 + (wave == 2 ? 8 : (wave == 3 ? 4 : 2)); }
+                    const int part = n0 >= 12 ? 1 : 0, quad = lane >> 2, l4 = lane & 3;
+                    float4 h4[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {            // lane (quad, j): stream j's values of input block 16 * (3 part + u) + quad
+                        const int blk = 16 * (3 * part + u) + quad;
+                        h4[u] = *(const float4 *)(smem + L::hA + blk * L::HA_STRIDE + (blk >> 2) * 16 + l4 * 16);
+                    }
+                    // lane (quad, i): row 4 rq + i, block 48 part + 16 u + quad of the swizzled image (see the LDS fill)
+                    const unsigned char *wq0 = smem + L::bw + ((48 * part + quad) * 4 + l4) * 16;
+                    auto ldw = [&](const int n, float4 (&w)[3]) {
+                        const unsigned char *q = wq0 + (n - 12 * part) * (96 * 64);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) w[u] = *(const float4 *)(q + u * 1024);
+                    };
+                    float4 wc[3], wn[3];
+                    ldw(n0, wc);
+                    for (int n = n0; n < n1; ++n) {
+                        ldw(n + 1 < n1 ? n + 1 : n, wn);     // next unit's weights under this unit's MFMAs
+                        f4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};     // two chains: a dependent MFMA waits for its predecessor
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            da = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].x, h4[u].x, da, 0, 0, 0);
+                            db = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].y, h4[u].y, db, 0, 0, 0);
+                            da = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].z, h4[u].z, da, 0, 0, 0);
+                            db = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].w, h4[u].w, db, 0, 0, 0);
+                        }
+                        // register k of lane (quad, j) = row 4 rq + k x stream j, this quad's columns: fold the four quads of a 16-lane row
+                        // (element-wise copies first: hipcc's __builtin_bit_cast of an ext-vector ELEMENT reads element 0 whatever the index)
+                        float dk[4] = {da[0] + db[0], da[1] + db[1], da[2] + db[2], da[3] + db[3]};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            dk[k] = dk[k] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dk[k]), 0x114, 0xf, 0xf, true));
+                            dk[k] = dk[k] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dk[k]), 0x118, 0xf, 0xf, true));
+                        }
+                        if ((lane & 15) >= 12 && l4 < S) {   // [row][stream][half][lane row]: 8 partial sums side by side
+                            float *o = sm_inh + (((n - 12 * part) * 4) * S + l4) * 8 + part * 4 + (lane >> 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) o[k * S * 8] = dk[k];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) wc[u] = wn[u];
+                    }
+                    lds_arrive();
+                }
+            }
+            const bool gb_fsplit = FAST && !I8 && b_dense && S <= LPCN_WAVES / 2 && !gb_mfma;
             int gb_qa = 24;
             if constexpr (FAST && !I8) {
                 const int hw = wave < LPCN_WAVES / 2 ? wave + LPCN_WAVES / 2 : wave;       // the helper wave of this pair
@@ -1227,6 +1317,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         }
                     }
                     zrh = zrh * QS1;
+                } else if (gb_mfma) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) rec = __builtin_fmaf(sm_brec[j * RB + r], sm_hB[s * NB + j], rec);
+                    mirror_wait();                           // all eight waves' partial sums are in LDS
+                    const float4 pa = *(const float4 *)(sm_inh + (r * S + s) * 8), pb = *(const float4 *)(sm_inh + (r * S + s) * 8 + 4);
+                    zrh = zrh + (((pa.x + pa.y) + (pa.z + pa.w)) + ((pb.x + pb.y) + (pb.z + pb.w)));
+                    (void)g; (void)ri;
                 } else if (gb_fsplit) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j) rec = __builtin_fmaf(sm_brec[j * RB + r], sm_hB[s * NB + j], rec);
@@ -1441,18 +1538,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 if (tap == 0 && live) ((int *)sm_lead)[lrow * 8 + 2] = exc;
                 if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live) {
-                    float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
+                    LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
                     d[1] = (float)(sm_idx[0] & 0xFF); d[2] = (float)((sm_idx[0] >> 8) & 0xFF);
                 }
                 // the next sample's indices first: the other waves are waiting for them
                 if (more) { open_sample(live, pcm, tap == 0 ? pcm * lpc_tap : prod_old, exc, false); publish_indices(); }
                 if (LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(0);
                 if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live)
-                    Ap->dbg[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 405] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_b4);
+                    as_global_rw(Ap->dbg)[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 405] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_b4);
                 if (tap == 0) {
                     if (live) {
                         if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
-                            float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
+                            LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
                             d[0] = (float)exc; d[3] = pcm + 0.85f * deemph; d[4] = pcm - sm_ulaw[exc];
                             // the tree's own decision (teacher forcing overrides exc) is walked AGAIN here, in the cold trace branch:
                             // any use of the leader's value this far down (a register, an extra LDS store) cost 17 spilled
@@ -1470,7 +1567,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             }
             if (more && tid >= 64 && tid < 64 + S && live) draw_thresholds(tid - 64);
             if (Ap->dbg && blockIdx.x == 0) {
-                float *d = Ap->dbg + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE;
+                LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE;
                 if (tid < NA) d[tid] = sm_hT[tid * S];
                 if (tid < NB) d[384 + tid] = sm_hB[tid];
             }
