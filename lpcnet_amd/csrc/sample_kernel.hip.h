@@ -371,6 +371,27 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const bool b_dense = Ap->b_dense != 0;
     // PARITY, float blob, dense GRU-B input matrix: GRU-B takes the GRU-A state through scalar loads (see grub_scalar_loop.inc)
     const bool gb_scalar = !I8 && !FAST && b_dense && Ap->hmir != nullptr;
+    // Argument-block members the sample loop needs on its critical path, fetched ONCE and made opaque: left to itself the
+    // compiler re-reads them with a scalar load at every use (cheaper than keeping an SGPR, it thinks), and a scalar load in
+    // flight forces every LDS wait behind it to lgkmcnt(0) -- right behind a barrier that is a stall for every wave (int8:
+    // 148 -> 154.5 M samples/s).  A spilled SGPR comes back with one v_readlane.  The PARITY float kernels are the
+    // exception: they have no SGPR to spare (the scalar-state GRU-B owns 36), and the ten more spilled ones cost what the
+    // loads did (109.5 M without, 108.7 M with) -- they keep the plain member reads.
+    constexpr bool HOIST = I8 || FAST;
+    int tracing_s = 0;                                       // tests only: workgroup 0 writes the per-sample trace
+    if constexpr (HOIST) { tracing_s = __builtin_amdgcn_readfirstlane((Ap->dbg != nullptr && blockIdx.x == 0) ? 1 : 0); LPCN_REMAT_S(tracing_s); }
+// (the non-hoisted forms spell the tests exactly as before: the PARITY float kernels' register allocation is that fragile)
+#define tracing (HOIST ? tracing_s != 0 : (Ap->dbg && blockIdx.x == 0))
+#define tracing_any (HOIST ? tracing_s != 0 : Ap->dbg != nullptr)
+#define tracing_lane0(extra) (HOIST ? (tracing_s != 0 && tid == 0 && (extra)) : (Ap->dbg && tid == 0 && blockIdx.x == 0 && (extra)))
+    const LPCN_GLOBAL float *fc_w_s = nullptr, *fc_b_s = nullptr, *fc_f_s = nullptr;
+    if constexpr (HOIST) {
+        fc_w_s = as_global(Ap->fc_w); fc_b_s = as_global(Ap->fc_b); fc_f_s = as_global(Ap->fc_f);
+        asm volatile("" : "+s"(fc_w_s), "+s"(fc_b_s), "+s"(fc_f_s));
+    }
+#define fc_w_g (HOIST ? fc_w_s : as_global(Ap->fc_w))
+#define fc_b_g (HOIST ? fc_b_s : as_global(Ap->fc_b))
+#define fc_f_g (HOIST ? fc_f_s : as_global(Ap->fc_f))
     // bit k: this wave owns rows in slot k (wave-uniform)
     const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row[1] >= 0) != 0ull ? 2 : 0) |
                                                         (__ballot(row[2] >= 0) != 0ull ? 4 : 0));
@@ -964,7 +985,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_PROF(6);      // slots: begin + items + end
             __syncthreads();                                                   // B1
             LPCN_PROF(0);
-            if (Ap->dbg && blockIdx.x == 0) {                                  // tests: recurrent pre-activations of stream 0
+            if (tracing) {                                                     // tests: recurrent pre-activations of stream 0
                 LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 448;
                 for (int i = tid0; i < RA; i += LPCN_WG_THREADS) d[i] = sm_pre[i * S];
             }
@@ -1029,7 +1050,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // (tried: the GRU-B waves issue these loads only after their mat-vec -- the ~0.1 k clk saved in front of GRU-B
             // come back as a later tree phase: 102.3 vs 102.2 M samples/s, not kept)
             const int node = tid >> 1, chan = tid & 1;
-            const auto *fcw_ptr = as_global(Ap->fc_w) + node * 2 * NB + chan * NB;
+            const auto *fcw_ptr = fc_w_g + node * 2 * NB + chan * NB;
             float fcw[NB];
             bool fc_f16 = false;
             if constexpr (FAST) {
@@ -1048,7 +1069,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
                 for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
             }
-            const float fcb = as_global(Ap->fc_b)[chan * 256 + node], fcf = as_global(Ap->fc_f)[chan * 256 + node];
+            const float fcb = fc_b_g[chan * 256 + node], fcf = fc_f_g[chan * 256 + node];
             LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
             // FAST, int8 blobs, dense input matrix: integer block sums are exact in any order, so the 96 input blocks of a
@@ -1484,7 +1505,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             const bool more = smp + 1 < frame_len;
             if (more) ++seq;
             unsigned long long t_b4 = 0;
-            if (Ap->dbg) t_b4 = __builtin_amdgcn_s_memtime();                 // tests: leader latency barrier -> publish
+            if (tracing_any) t_b4 = __builtin_amdgcn_s_memtime();                 // tests: leader latency barrier -> publish
 #ifndef LPCN_LEADER_PRIO
 #define LPCN_LEADER_PRIO 3
 #endif
@@ -1537,18 +1558,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     hist = live ? shifted : hist;
                 }
                 if (tap == 0 && live) ((int *)sm_lead)[lrow * 8 + 2] = exc;
-                if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live) {
+                if (tracing_lane0(live)) {
                     LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
                     d[1] = (float)(sm_idx[0] & 0xFF); d[2] = (float)((sm_idx[0] >> 8) & 0xFF);
                 }
                 // the next sample's indices first: the other waves are waiting for them
                 if (more) { open_sample(live, pcm, tap == 0 ? pcm * lpc_tap : prod_old, exc, false); publish_indices(); }
                 if (LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(0);
-                if (Ap->dbg && tid == 0 && blockIdx.x == 0 && live)
+                if (tracing_lane0(live))
                     as_global_rw(Ap->dbg)[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 405] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_b4);
                 if (tap == 0) {
                     if (live) {
-                        if (Ap->dbg && tid == 0 && blockIdx.x == 0) {
+                        if (tracing_lane0(true)) {
                             LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
                             d[0] = (float)exc; d[3] = pcm + 0.85f * deemph; d[4] = pcm - sm_ulaw[exc];
                             // the tree's own decision (teacher forcing overrides exc) is walked AGAIN here, in the cold trace branch:
@@ -1566,7 +1587,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
             }
             if (more && tid >= 64 && tid < 64 + S && live) draw_thresholds(tid - 64);
-            if (Ap->dbg && blockIdx.x == 0) {
+            if (tracing) {
                 LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE;
                 if (tid < NA) d[tid] = sm_hT[tid * S];
                 if (tid < NB) d[384 + tid] = sm_hB[tid];
@@ -1620,5 +1641,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         }
     }
 }
+
+#undef tracing
+#undef tracing_any
+#undef tracing_lane0
+#undef fc_w_g
+#undef fc_b_g
+#undef fc_f_g
 
 }  // namespace lpcn
