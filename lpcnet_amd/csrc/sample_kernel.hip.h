@@ -1108,63 +1108,62 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // FAST, float blobs, dense input matrix, S >= 2: the input mat-vec of ALL streams of the workgroup is one small GEMM,
             // [48 rows x 384] x [384 x S], on the matrix pipe.  v_mfma_f32_4x4x1_16B: each of the 16 quads of a wave forms a
             // (4 rows) x (4 streams) outer product for ITS input column and accumulates it, so one instruction covers 16
-            // columns; a unit = (row quad, half of the 384 columns) = 3 weight reads + 3 state reads (16 bytes per lane, the
-            // state straight out of the layout the other paths use) + 12 MFMAs.  The 24 units are dealt unevenly: the waves
-            // that run a candidate head afterwards take two, the gate waves (which only have the recurrent part and the
-            // gates left) more.  The 16 quads' sums are folded with two DPP row shifts, the remaining 4 rows x 2 halves meet
-            // in LDS (sm_inh is idle in this phase) and the stream's gate wave adds them up.  No workgroup barrier: every wave
-            // bumps the arrival counter behind its LDS stores (LDS operations of a wave complete in order) and goes on; only
-            // the gate waves wait for all eight.  ~2 k clk of GRU-B instead of ~6 k for one FMA chain per stream.
+            // columns; a unit = one row quad over all 384 columns = 6 weight reads + 6 state reads (16 bytes per lane, the
+            // state straight out of the layout the other paths use) + 24 MFMAs in two chains.  The 12 units go to the waves
+            // that have no candidate head to run (S = 4: three per gate wave).  The 16 quads' sums are folded with two DPP
+            // row shifts, the remaining 4 lane rows meet in LDS (sm_inh is idle in this phase) and the stream's gate wave adds
+            // them up.  No workgroup barrier: every wave bumps the arrival counter behind its LDS stores (LDS operations of a
+            // wave complete in order) and goes on; only the gate waves wait for all eight.  ~1.2 k clk of GRU-B mat-vec
+            // instead of ~6 k for one FMA chain per stream.
             const bool gb_mfma = FAST && !I8 && b_dense && S >= 2;
             if constexpr (FAST && !I8 && S >= 2) {
                 if (b_dense) {                               // (workgroup-uniform)
                     typedef float f4 __attribute__((ext_vector_type(4)));
                     ++gbseq;
-                    // unit n = (column half n / 12, row quad n % 12); a wave's units lie in one half
-                    int n0, n1;
-                    if constexpr (S == 4) { n0 = wave < 4 ? 4 * wave : 8 + 2 * wave; n1 = n0 + (wave < 4 ? 4 : 2); }
-                    else { n0 = wave < 2 ? 2 * wave : (wave == 2 ? 4 : (wave == 3 ? 12 : 8 + 2 * wave)); n1 = n0 + (wave == 2 ? 8 : (wave == 3 ? 4 : 2)); }
-                    const int part = n0 >= 12 ? 1 : 0, quad = lane >> 2, l4 = lane & 3;
-                    float4 h4[3];
+                    int n0, n1;                              // this wave's row quads
+                    if constexpr (S == 4) { n0 = 3 * wave; n1 = wave < 4 ? n0 + 3 : n0; }
+                    else { n0 = wave < 2 ? 2 * wave : 4 * wave - 4; n1 = wave < 2 ? n0 + 2 : (wave < 4 ? n0 + 4 : n0); }
+                    if (n0 < n1) {                           // (wave-uniform)
+                        const int quad = lane >> 2, l4 = lane & 3;
+                        // lane (quad, j): stream j's values of input block 16 u + quad; lane (quad, i): row 4 rq + i of the same block
+                        // in the swizzled weight image (see the LDS fill)
+                        const unsigned char *hq0 = smem + L::hA + quad * L::HA_STRIDE + (quad >> 2) * 16 + l4 * 16;
+                        const unsigned char *wq0 = smem + L::bw + (quad * 4 + l4) * 16;
+                        for (int n = n0; n < n1; ++n) {
+                            const unsigned char *wq = wq0 + n * (96 * 64);
+                            f4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};     // two chains: a dependent MFMA waits for its predecessor
+                            // reads two steps ahead of the matrix pipe (scheduling barriers: hipcc otherwise sinks every read to its use)
+                            float4 wr[3], hr[3];
+                            wr[0] = *(const float4 *)(wq); hr[0] = *(const float4 *)(hq0);
+                            wr[1] = *(const float4 *)(wq + 1024); hr[1] = *(const float4 *)(hq0 + (16 * L::HA_STRIDE + 64));
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) {            // lane (quad, j): stream j's values of input block 16 * (3 part + u) + quad
-                        const int blk = 16 * (3 * part + u) + quad;
-                        h4[u] = *(const float4 *)(smem + L::hA + blk * L::HA_STRIDE + (blk >> 2) * 16 + l4 * 16);
-                    }
-                    // lane (quad, i): row 4 rq + i, block 48 part + 16 u + quad of the swizzled image (see the LDS fill)
-                    const unsigned char *wq0 = smem + L::bw + ((48 * part + quad) * 4 + l4) * 16;
-                    auto ldw = [&](const int n, float4 (&w)[3]) {
-                        const unsigned char *q = wq0 + (n - 12 * part) * (96 * 64);
+                            for (int u = 0; u < 6; ++u) {
+                                if (u + 2 < 6) {
+                                    wr[(u + 2) % 3] = *(const float4 *)(wq + (u + 2) * 1024);
+                                    hr[(u + 2) % 3] = *(const float4 *)(hq0 + (u + 2) * (16 * L::HA_STRIDE + 64));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                const float4 w4 = wr[u % 3], hv = hr[u % 3];
+                                da = __builtin_amdgcn_mfma_f32_4x4x1f32(w4.x, hv.x, da, 0, 0, 0);
+                                db = __builtin_amdgcn_mfma_f32_4x4x1f32(w4.y, hv.y, db, 0, 0, 0);
+                                da = __builtin_amdgcn_mfma_f32_4x4x1f32(w4.z, hv.z, da, 0, 0, 0);
+                                db = __builtin_amdgcn_mfma_f32_4x4x1f32(w4.w, hv.w, db, 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            // register k of lane (quad, j) = row 4 rq + k x stream j, this quad's columns: fold the four quads of a 16-lane row
+                            // (element-wise copies first: hipcc's __builtin_bit_cast of an ext-vector ELEMENT reads element 0 whatever the index)
+                            float dk[4] = {da[0] + db[0], da[1] + db[1], da[2] + db[2], da[3] + db[3]};
 #pragma unroll
-                        for (int u = 0; u < 3; ++u) w[u] = *(const float4 *)(q + u * 1024);
-                    };
-                    float4 wc[3], wn[3];
-                    ldw(n0, wc);
-                    for (int n = n0; n < n1; ++n) {
-                        ldw(n + 1 < n1 ? n + 1 : n, wn);     // next unit's weights under this unit's MFMAs
-                        f4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};     // two chains: a dependent MFMA waits for its predecessor
+                            for (int k = 0; k < 4; ++k) {
+                                dk[k] = dk[k] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dk[k]), 0x114, 0xf, 0xf, true));
+                                dk[k] = dk[k] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dk[k]), 0x118, 0xf, 0xf, true));
+                            }
+                            if ((lane & 15) >= 12 && l4 < S) {   // [row][stream][lane row]: 4 partial sums side by side
+                                float *o = sm_inh + ((n * 4) * S + l4) * 4 + (lane >> 4);
 #pragma unroll
-                        for (int u = 0; u < 3; ++u) {
-                            da = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].x, h4[u].x, da, 0, 0, 0);
-                            db = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].y, h4[u].y, db, 0, 0, 0);
-                            da = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].z, h4[u].z, da, 0, 0, 0);
-                            db = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[u].w, h4[u].w, db, 0, 0, 0);
+                                for (int k = 0; k < 4; ++k) o[k * S * 4] = dk[k];
+                            }
                         }
-                        // register k of lane (quad, j) = row 4 rq + k x stream j, this quad's columns: fold the four quads of a 16-lane row
-                        // (element-wise copies first: hipcc's __builtin_bit_cast of an ext-vector ELEMENT reads element 0 whatever the index)
-                        float dk[4] = {da[0] + db[0], da[1] + db[1], da[2] + db[2], da[3] + db[3]};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            dk[k] = dk[k] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dk[k]), 0x114, 0xf, 0xf, true));
-                            dk[k] = dk[k] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dk[k]), 0x118, 0xf, 0xf, true));
-                        }
-                        if ((lane & 15) >= 12 && l4 < S) {   // [row][stream][half][lane row]: 8 partial sums side by side
-                            float *o = sm_inh + (((n - 12 * part) * 4) * S + l4) * 8 + part * 4 + (lane >> 4);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) o[k * S * 8] = dk[k];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) wc[u] = wn[u];
                     }
                     lds_arrive();
                 }
@@ -1342,8 +1341,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
                     for (int j = 0; j < NB; ++j) rec = __builtin_fmaf(sm_brec[j * RB + r], sm_hB[s * NB + j], rec);
                     mirror_wait();                           // all eight waves' partial sums are in LDS
-                    const float4 pa = *(const float4 *)(sm_inh + (r * S + s) * 8), pb = *(const float4 *)(sm_inh + (r * S + s) * 8 + 4);
-                    zrh = zrh + (((pa.x + pa.y) + (pa.z + pa.w)) + ((pb.x + pb.y) + (pb.z + pb.w)));
+                    const float4 pa = *(const float4 *)(sm_inh + (r * S + s) * 4);
+                    zrh = zrh + ((pa.x + pa.y) + (pa.z + pa.w));
                     (void)g; (void)ri;
                 } else if (gb_fsplit) {
 #pragma unroll
