@@ -1054,17 +1054,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             float fcw[NB];
             bool fc_f16 = false;
             if constexpr (FAST) {
+                // fp16 sub-option: 8 dwords of fp16 pairs per row instead of 16 floats.  Both forms issue the same 16 loads from two
+                // row halves (the second half is a dead copy of the first for fp16): a branch here would merge the two register
+                // sets with copies, and the copies would wait for the loads -- in front of GRU-B.
                 fc_f16 = Ap->fc_f16 != 0;
-                if (fc_f16) {                                // 8 dwords of fp16 pairs instead of 16 floats
-                    const auto *wh = as_global(Ap->fc_wh) + (node * 2 + chan) * (NB / 2);
+                const auto *lo = fc_f16 ? (const LPCN_GLOBAL float *)(as_global(Ap->fc_wh) + (node * 2 + chan) * (NB / 2)) : fcw_ptr;
+                const auto *hi = fc_f16 ? lo : fcw_ptr + NB / 2;
 #pragma unroll
-                    for (int j = 0; j < NB / 2; ++j) fcw[j] = __builtin_bit_cast(float, wh[j]);
-#pragma unroll
-                    for (int j = NB / 2; j < NB; ++j) fcw[j] = 0.f;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
-                }
+                for (int j = 0; j < NB / 2; ++j) { fcw[j] = lo[j]; fcw[NB / 2 + j] = hi[j]; }
             } else {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
