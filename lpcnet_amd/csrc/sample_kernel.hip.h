@@ -45,6 +45,17 @@
 //   The mirror stores of P2 are not waited for at B2: every wave bumps an LDS arrival counter once its stores are
 //   acknowledged by L2, and a GRU-B wave starts its scalar loads when all eight have arrived (it forms the recurrent part
 //   meanwhile).
+//
+// FAST (lpcnet_batch_set_fast) frees the order of a row's sum, and the kernel then uses the matrix pipe: a GRU-A item is
+// four v_mfma_f32_4x4x1 (4 rows' weights x 4 streams' state values per quad), and -- float blobs, dense GRU-B -- the GRU-B
+// input mat-vec of all S streams is one [48 x 384] x [384 x S] GEMM on the gate waves (see gb_mfma in P3).
+//
+// Two things the compiler does to this kernel that cost more than any instruction in it (both found in the assembly):
+//   * a FLAT store anywhere in the sample loop (the test trace, through a generic pointer) makes SIInsertWaitcnts force
+//     every later LDS wait to lgkmcnt(0) until both counters have been drained: the state prefetch of the item chains no
+//     longer overlapped anything.  All trace stores go through address-space-1 pointers.
+//   * a member of the argument block read inside the loop is a scalar load, and a scalar load in flight forces lgkmcnt(0)
+//     as well (SMEM returns out of order); see HOIST below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -861,7 +872,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     constexpr int j = decltype(jc)::value;
                     if constexpr (j < NW) {
                         if constexpr (j + PF < NW) fetch_h(j + PF);
-                        if (j >= e0) mac(j);
+                        if (j >= e0) { asm volatile(""); mac(j); }       // (the empty statement keeps this a scalar branch: if-converted, int8 items became
+                                                                        // selects on 24 precomputed lane masks -- 48 SGPRs, most of them spilled)
                         self(self, std::integral_constant<int, j + 1>{});
                     }
                 };
@@ -1051,22 +1063,28 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // come back as a later tree phase: 102.3 vs 102.2 M samples/s, not kept)
             const int node = tid >> 1, chan = tid & 1;
             const auto *fcw_ptr = fc_w_g + node * 2 * NB + chan * NB;
-            float fcw[NB];
+            float fcw[NB], fcb = 0.f, fcf = 0.f;
             bool fc_f16 = false;
-            if constexpr (FAST) {
-                // fp16 sub-option: 8 dwords of fp16 pairs per row instead of 16 floats.  Both forms issue the same 16 loads from two
-                // row halves (the second half is a dead copy of the first for fp16): a branch here would merge the two register
-                // sets with copies, and the copies would wait for the loads -- in front of GRU-B.
-                fc_f16 = Ap->fc_f16 != 0;
-                const auto *lo = fc_f16 ? (const LPCN_GLOBAL float *)(as_global(Ap->fc_wh) + (node * 2 + chan) * (NB / 2)) : fcw_ptr;
-                const auto *hi = fc_f16 ? lo : fcw_ptr + NB / 2;
+            auto load_fc = [&]() __attribute__((always_inline)) {
+                if constexpr (FAST) {
+                    // fp16 sub-option: 8 dwords of fp16 pairs per row instead of 16 floats.  Both forms issue the same 16 loads from two
+                    // row halves (the second half is a dead copy of the first for fp16): a branch here would merge the two register
+                    // sets with copies, and the copies would wait for the loads -- in front of GRU-B.
+                    fc_f16 = Ap->fc_f16 != 0;
+                    const auto *lo = fc_f16 ? (const LPCN_GLOBAL float *)(as_global(Ap->fc_wh) + (node * 2 + chan) * (NB / 2)) : fcw_ptr;
+                    const auto *hi = fc_f16 ? lo : fcw_ptr + NB / 2;
 #pragma unroll
-                for (int j = 0; j < NB / 2; ++j) { fcw[j] = lo[j]; fcw[NB / 2 + j] = hi[j]; }
-            } else {
+                    for (int j = 0; j < NB / 2; ++j) { fcw[j] = lo[j]; fcw[NB / 2 + j] = hi[j]; }
+                } else {
 #pragma unroll
-                for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
-            }
-            const float fcb = fc_b_g[chan * 256 + node], fcf = fc_f_g[chan * 256 + node];
+                    for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
+                }
+                fcb = fc_b_g[chan * 256 + node]; fcf = fc_f_g[chan * 256 + node];
+            };
+            // (FAST kernels with two workgroups per CU -- 128 VGPRs -- fetch the row only when the tree needs it: 18 registers live
+            // across GRU-B pushed loop invariants into scratch there, and the other workgroup covers the load latency)
+            constexpr bool FC_LATE = PACK2 && FAST;
+            if constexpr (!FC_LATE) load_fc();
             LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
             // FAST, int8 blobs, dense input matrix: integer block sums are exact in any order, so the 96 input blocks of a
@@ -1452,6 +1470,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_PROF(2);
 
             // ------------------------------------------ P4: dual-FC tree, all nodes at once --
+            if constexpr (FC_LATE) load_fc();
             {
                 const int node_level = node > 0 ? 31 - __clz(node) : 0;
                 // (tried: the S x 16 GRU-B state values through one LDS read per lane + v_readlane into SGPR operands instead of

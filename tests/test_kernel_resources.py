@@ -54,11 +54,22 @@ def test_fast_fmac_dpp_hazards(rows, tmp_path_factory):
     import kernel_resources as kr
     for key, r in rows.items():
         if key[2] and not key[1]:
-            assert r["fmac_dpp"] >= 16 and r["dpp_hazard_violations"] == 0, key     # (GRU-B's split loop; GRU-A's items use the matrix pipe)
+            assert r["dpp_hazard_violations"] == 0, key     # (S >= 2: GRU-B and GRU-A both run on the matrix pipe, the DPP loop is gone)
     for sv in (1, 2):
         path = str(tmp_path_factory.mktemp(f"asm_s{sv}") / f"sample_s{sv}.s")
         kr.compile_asm(sv, path)
         fast_float = [r for r in kr.analyse(path) if r["fast"] and not r["int8"]]
         assert len(fast_float) == 6
         for r in fast_float:
-            assert r["fmac_dpp"] >= 16 and r["dpp_hazard_violations"] == 0, (sv, r["NW"], r["dpp_hazard_violations"])
+            assert (r["fmac_dpp"] >= 16 or sv > 1) and r["dpp_hazard_violations"] == 0, (sv, r["NW"], r["dpp_hazard_violations"])
+
+
+def test_nothing_in_the_sample_loop_forces_full_lds_waits(rows):
+    """round 3: a FLAT store in the loop (the trace, through a generic pointer) made the compiler wait with lgkmcnt(0) in every
+    item of the GRU-A chains; and a register allocation that reloads ~110 spilled SGPRs per sample (v_readlane) instead of
+    ~15 costs the benchmarked float kernel 2.3 % -- it has come and gone with one-line changes, so it is pinned here"""
+    for key, r in rows.items():
+        assert r["flat_insts_in_sample_loop"] == 0, key
+    assert rows[(30, False, False)]["sgpr_reloads_in_sample_loop"] <= 40, rows[(30, False, False)]
+    for key in [(32, True, False), (32, True, True), (30, False, True)]:
+        assert rows[key]["sgpr_reloads_in_sample_loop"] <= 10, (key, rows[key])

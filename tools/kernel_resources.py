@@ -68,6 +68,7 @@ def analyse(asm_path):
         in_loop = None
         loop_lines = None
         sgpr_reloads = None
+        flat_in_loop = None
         if ends:
             end = ends[-1]
             # the loop's backward branch: first branch after the marker whose target label lies before the marker
@@ -83,6 +84,8 @@ def analyse(asm_path):
                 loop_lines = len(region)
                 # spilled SGPRs live in VGPR lanes: every reload in the loop is a v_readlane_b32 (plus its hazard wait states)
                 sgpr_reloads = sum(1 for ln in region if re.search(r"\bv_readlane_b32", ln))
+                # a FLAT access in the loop makes the compiler force every later LDS wait to lgkmcnt(0) (see sample_kernel.hip.h)
+                flat_in_loop = sum(1 for ln in region if re.search(r"^\s+flat_(load|store|atomic)", ln))
         # DPP read-after-VALU-write hazard of the hand-written v_fmac_f32_dpp (the assembler's hazard recogniser cannot
         # see inside inline asm): its DPP source must not be written by a VALU instruction in the two preceding slots
         dpp_viol = 0
@@ -102,7 +105,7 @@ def analyse(asm_path):
                 if re.match(r"v_cmpx", prev) or re.match(r"s_\w+ exec(_lo|_hi)?,", prev) or re.match(r"s_\w+saveexec", prev):
                     dpp_viol += 1
         total = sum(1 for ln in body if re.search(r"\bscratch_(load|store)", ln))
-        rec = dict(name=name, **info, **meta.get(name, {}), scratch_insts=total, scratch_insts_in_sample_loop=in_loop, sample_loop_asm_lines=loop_lines, sgpr_reloads_in_sample_loop=sgpr_reloads,
+        rec = dict(name=name, **info, **meta.get(name, {}), scratch_insts=total, scratch_insts_in_sample_loop=in_loop, sample_loop_asm_lines=loop_lines, sgpr_reloads_in_sample_loop=sgpr_reloads, flat_insts_in_sample_loop=flat_in_loop,
                    fmac_dpp=sum(1 for i in insts if i.startswith("v_fmac_f32_dpp")), dpp_hazard_violations=dpp_viol)
         out.append(rec)
     return sorted(out, key=lambda r: (r["S"], r["int8"], r["fast"], r["pack2"], r["NW"]))
@@ -123,10 +126,10 @@ def main():
         print(json.dumps(rows, indent=1))
         return
     print(f"# {path}")
-    print("S NW int8 fast (+ = two workgroups per CU) | vgpr sgpr vgpr_spill sgpr_spill scratch_B | scratch insts: total / in sample loop (loop asm lines) | SGPR reloads (v_readlane) in sample loop")
+    print("S NW int8 fast (+ = two workgroups per CU) | vgpr sgpr vgpr_spill sgpr_spill scratch_B | scratch insts: total / in sample loop (loop asm lines) | SGPR reloads (v_readlane), FLAT instructions in sample loop")
     for r in rows:
         print(f"{r['S']} {r['NW']:2d} {int(r['int8'])}    {int(r['fast'])}{'+' if r['pack2'] else ' '}   | {r.get('vgpr', -1):4d} {r.get('sgpr', -1):4d} {r.get('vgpr_spill', -1):6d} {r.get('sgpr_spill', -1):10d} "
-              f"{r.get('scratch_bytes', -1):9d} | {r['scratch_insts']:3d} / {r['scratch_insts_in_sample_loop']} ({r['sample_loop_asm_lines']}) | {r['sgpr_reloads_in_sample_loop']}"
+              f"{r.get('scratch_bytes', -1):9d} | {r['scratch_insts']:3d} / {r['scratch_insts_in_sample_loop']} ({r['sample_loop_asm_lines']}) | {r['sgpr_reloads_in_sample_loop']}, {r['flat_insts_in_sample_loop']}"
               + (f" | v_fmac_f32_dpp {r['fmac_dpp']}, hazard violations {r['dpp_hazard_violations']}" if r['fmac_dpp'] else ""))
 
 
