@@ -1081,10 +1081,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 fcb = fc_b_g[chan * 256 + node]; fcf = fc_f_g[chan * 256 + node];
             };
-            // (FAST kernels with two workgroups per CU -- 128 VGPRs -- fetch the row only when the tree needs it: 18 registers live
-            // across GRU-B pushed loop invariants into scratch there, and the other workgroup covers the load latency)
-            constexpr bool FC_LATE = PACK2 && FAST;
-            if constexpr (!FC_LATE) load_fc();
+            // (tried on the 128-VGPR FAST kernels: fetching the row only when the tree needs it -- 160 vs 168 M samples/s on int8)
+            load_fc();
             LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
             // FAST, int8 blobs, dense input matrix: integer block sums are exact in any order, so the 96 input blocks of a
@@ -1470,7 +1468,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_PROF(2);
 
             // ------------------------------------------ P4: dual-FC tree, all nodes at once --
-            if constexpr (FC_LATE) load_fc();
             {
                 const int node_level = node > 0 ? 31 - __clz(node) : 0;
                 // (tried: the S x 16 GRU-B state values through one LDS read per lane + v_readlane into SGPR operands instead of
