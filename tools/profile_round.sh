@@ -34,5 +34,7 @@ if [ -f lpcnet_amd/liblpcnet_hip_prof.so ]; then
   LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1:1 > $OUT/phase_f32.log 2>&1
   LPCNET_HIP_NO_SCALAR_GRUB=1 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32_lds_state_grub.log 2>&1
   LPCN_FLAVOUR=int8 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1024:2 > $OUT/phase_i8.log 2>&1
+  LPCN_FAST=1 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32_fast.log 2>&1
+  LPCN_FAST=1 LPCN_FLAVOUR=int8 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:2 > $OUT/phase_i8_fast.log 2>&1
 fi
 find $OUT -name "*.csv" | head -40

@@ -57,7 +57,7 @@ for fl, suffix in (("f32", ""), ("i8", "_int8")):
     b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
     if os.path.exists(b):
         shutil.copy(b, os.path.join(DST, f"{RND}_sq_counters{suffix}.csv"))
-ph = [os.path.join(SRC, f) for f in ("phase_f32.log", "phase_f32_lds_state_grub.log", "phase_i8.log") if os.path.exists(os.path.join(SRC, f))]
+ph = [os.path.join(SRC, f) for f in ("phase_f32.log", "phase_f32_lds_state_grub.log", "phase_i8.log", "phase_f32_fast.log", "phase_i8_fast.log") if os.path.exists(os.path.join(SRC, f))]
 if ph:
     with open(os.path.join(DST, f"{RND}_phase_clocks.txt"), "w") as o:
         o.write("# in-kernel s_memtime phase table (profiling build: LPCN_PROF_MASK=0xFFF python -m lpcnet_amd.build --prof; LPCNET_HIP_LIB=.../liblpcnet_hip_prof.so\n"
