@@ -55,6 +55,7 @@ def main():
     out_dir = os.path.join(ROOT, "gpurun_out", "sq")
     os.makedirs(out_dir, exist_ok=True)
     os.environ["TMPDIR"] = "/tmp"
+    os.environ["LPCNET_HIP_NO_AUTOTUNE"] = "1"            # only the workload's launches: the auto-tune's short trial launches of every variant would be averaged in
     av = available()
     have = None
     if av:
