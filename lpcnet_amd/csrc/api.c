@@ -978,6 +978,18 @@ int lpcnet_hip_check_model(const unsigned char *data, int len, int *info)
     lpcn_model_host m;
     if (lpcn_model_parse(&m, data, len) != 0) { set_err("malformed or incomplete DNNw weight blob"); return -1; }
     int st = lpcn_model_selftest(&m);
+    if (!st) {                                           /* the FAST arithmetic's own GRU-A packing, where there is one (int8 blobs) */
+        lpcn_model_host f;
+        const int pf = lpcn_model_pack_fast(&m, &f);
+        if (pf < 0) st = 100;
+        else if (pf == 0) {
+            f.pk_b_w = m.pk_b_w; f.pk_b_wq = m.pk_b_wq; f.pk_b_start = m.pk_b_start; f.pk_b_blk = m.pk_b_blk;      /* (the check reads GRU-B's packing too: shared) */
+            const int sf = lpcn_model_selftest(&f);
+            if (sf) st = 100 + sf;
+            f.pk_b_w = NULL; f.pk_b_wq = NULL; f.pk_b_start = NULL; f.pk_b_blk = NULL;
+            lpcn_model_release(&f);
+        }
+    }
     if (info) { info[0] = m.is_int8; info[1] = m.nb_a; info[2] = m.nb_b; info[3] = m.nw; info[4] = m.nb_b_padded; info[5] = st; }
     lpcn_model_release(&m);
     if (st) { set_err("internal error: device packing inconsistent with blob"); return -1; }

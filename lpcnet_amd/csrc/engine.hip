@@ -44,6 +44,9 @@ struct lpcn_engine {
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     LpcnSampleArgs sargs{};        // model part filled at creation
+    LpcnSampleArgs sargs_fast{};   // the same with the FAST arithmetic's own GRU-A packing (int8 blobs: dealt without candidate heads)
+    bool has_fast_image = false;
+    int nw_variant_fast = 0;
     LpcnFrameModel fmodel{};
     lpcn::DecodeTables dec{};      // codec path: VQ codebooks + pitch table (set by lpcn_engine_set_codebooks)
     bool has_codebooks = false;
@@ -143,37 +146,43 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail(LPCN_E_HIP);
 
     LpcnSampleArgs &a = e->sargs;
-    // re-pad the item arrays from the model's nw to the compiled variant
-    {
-        const size_t item_dw = m->is_int8 ? 1 : 4;            // dwords per (lane, item)
-        const uint32_t *src = m->is_int8 ? (const uint32_t *)m->pk_a_wq : (const uint32_t *)m->pk_a_w;
-        std::vector<uint32_t> w((size_t)LPCN_WAVES * nwv * 64 * item_dw, 0u);
-        std::vector<uint8_t> b((size_t)LPCN_WAVES * nwv * 64, 0);
+    // GRU-A as dealt to waves and lanes (model_pack.c) + the embedding tables in that lane order: everything that depends on the dealing
+    auto upload_gru_a = [&](const lpcn_model_host *mm, LpcnSampleArgs &dst, int nwv_) -> int {
+        // re-pad the item arrays from the model's nw to the compiled variant
+        const size_t item_dw = mm->is_int8 ? 1 : 4;            // dwords per (lane, item)
+        const uint32_t *src = mm->is_int8 ? (const uint32_t *)mm->pk_a_wq : (const uint32_t *)mm->pk_a_w;
+        std::vector<uint32_t> w((size_t)LPCN_WAVES * nwv_ * 64 * item_dw, 0u);
+        std::vector<uint8_t> b((size_t)LPCN_WAVES * nwv_ * 64, 0);
         for (int wv = 0; wv < LPCN_WAVES; ++wv)
-            for (int j = 0; j < m->nw; ++j) {
+            for (int j = 0; j < mm->nw; ++j) {
                 // the early head of slot 0, [nw - head, nw) in the model, stays end-aligned in the compiled variant's item array
-                const int jd = j >= m->nw - m->pk_a_head[wv] ? j + (nwv - m->nw) : j;
-                memcpy(&w[((size_t)wv * nwv + jd) * 64 * item_dw], &src[((size_t)wv * m->nw + j) * 64 * item_dw], 64 * item_dw * 4);
-                memcpy(&b[((size_t)wv * nwv + jd) * 64], &m->pk_a_blk[((size_t)wv * m->nw + j) * 64], 64);
+                const int jd = j >= mm->nw - mm->pk_a_head[wv] ? j + (nwv_ - mm->nw) : j;
+                memcpy(&w[((size_t)wv * nwv_ + jd) * 64 * item_dw], &src[((size_t)wv * mm->nw + j) * 64 * item_dw], 64 * item_dw * 4);
+                memcpy(&b[((size_t)wv * nwv_ + jd) * 64], &mm->pk_a_blk[((size_t)wv * mm->nw + j) * 64], 64);
             }
         const uint32_t *d = nullptr;
-        if ((rc = upload<uint32_t>(e, &d, w.data(), w.size()))) return fail(rc);
-        a.a_w = (const float4 *)d;
-        if ((rc = upload<uint8_t>(e, &a.a_blk, b.data(), b.size()))) return fail(rc);
-    }
-    int bound[LPCN_WAVES * 4], allh[LPCN_WAVES * 3];
-    for (int wv = 0; wv < LPCN_WAVES; ++wv) {
-        for (int k = 0; k < 4; ++k) bound[wv * 4 + k] = m->pk_a_bound[wv][k];
-        for (int k = 0; k < 3; ++k) allh[wv * 3 + k] = m->pk_a_allh[wv][k];
-    }
+        int rc_ = 0;
+        if ((rc_ = upload<uint32_t>(e, &d, w.data(), w.size()))) return rc_;
+        dst.a_w = (const float4 *)d;
+        if ((rc_ = upload<uint8_t>(e, &dst.a_blk, b.data(), b.size()))) return rc_;
+        int bound[LPCN_WAVES * 4], allh[LPCN_WAVES * 3];
+        for (int wv = 0; wv < LPCN_WAVES; ++wv) {
+            for (int k = 0; k < 4; ++k) bound[wv * 4 + k] = mm->pk_a_bound[wv][k];
+            for (int k = 0; k < 3; ++k) allh[wv * 3 + k] = mm->pk_a_allh[wv][k];
+        }
+#define UPD(T, field, srcp, count) if ((rc_ = upload<T>(e, &dst.field, srcp, count))) return rc_
+        UPD(int, a_row, mm->pk_a_row, LPCN_WAVES * 3 * 64);
+        UPD(int, a_bound, bound, LPCN_WAVES * 4);
+        UPD(int, a_allh, allh, LPCN_WAVES * 3);
+        UPD(int, a_head, mm->pk_a_head, LPCN_WAVES);
+        UPD(float, emb_sig, mm->pk_emb[0], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+        UPD(float, emb_pred, mm->pk_emb[1], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+        UPD(float, emb_exc, mm->pk_emb[2], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+#undef UPD
+        return 0;
+    };
+    if ((rc = upload_gru_a(m, a, nwv))) return fail(rc);
 #define UP(T, field, src, count) if ((rc = upload<T>(e, &a.field, src, count))) return fail(rc)
-    UP(int, a_row, m->pk_a_row, LPCN_WAVES * 3 * 64);
-    UP(int, a_bound, bound, LPCN_WAVES * 4);
-    UP(int, a_allh, allh, LPCN_WAVES * 3);
-    UP(int, a_head, m->pk_a_head, LPCN_WAVES);
-    UP(float, emb_sig, m->pk_emb[0], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
-    UP(float, emb_pred, m->pk_emb[1], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
-    UP(float, emb_exc, m->pk_emb[2], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
     UP(float, a_bias1, m->a_bias + LPCN_ROWS_A, LPCN_ROWS_A);
     UP(float, a_diag, m->a_diag, LPCN_ROWS_A);
     if (m->is_int8) {
@@ -213,6 +222,23 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
 #undef UP
     a.nb_b = m->nb_b_padded;
     a.b_dense = m->b_dense;
+    {   // the FAST arithmetic's own GRU-A image where its best dealing is not PARITY's (int8 blobs)
+        lpcn_model_host mf;
+        const int pf = getenv("LPCNET_HIP_NO_FAST_IMAGE") ? 1 : lpcn_model_pack_fast(m, &mf);
+        if (pf < 0) { snprintf(g_err, sizeof(g_err), "packing the FAST image of GRU-A failed"); return fail(LPCN_E_MODEL); }
+        if (pf == 0) {
+            int nwf = 0;
+            for (const int *v = variants_i8; *v; ++v) if (mf.nw <= *v) { nwf = *v; break; }
+            if (nwf) {
+                e->sargs_fast = e->sargs;
+                rc = upload_gru_a(&mf, e->sargs_fast, nwf);
+                e->nw_variant_fast = nwf;
+                e->has_fast_image = rc == 0;
+            }
+            lpcn_model_release(&mf);
+            if (rc) return fail(rc);
+        }
+    }
 
     LpcnFrameModel &fm = e->fmodel;
 #define UPF(field, src, count) if ((rc = upload<float>(e, &fm.field, src, count))) return fail(rc)
@@ -311,7 +337,9 @@ static int device_cus(const lpcn_engine *e)
     if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
     return 256;
 }
-static bool pack2_available(const lpcn_engine *e) { return e->is_int8 && e->nw_variant <= 32; }
+// items per lane of the GRU-A image the engine's current arithmetic runs on
+static int cur_nw_variant(const lpcn_engine *e) { return (e->fast && e->has_fast_image) ? e->nw_variant_fast : e->nw_variant; }
+static bool pack2_available(const lpcn_engine *e) { return e->is_int8 && cur_nw_variant(e) <= 32; }
 static bool use_pack2(const lpcn_engine *e, int n, int S)
 {
     const char *force = getenv("LPCNET_HIP_PACK2");          // tools / tests: "0" never, "1" whenever the variant exists
@@ -476,7 +504,7 @@ extern "C" int lpcn_launch_sample_s4(int nw, int is_int8, int flags, int grid, i
 static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t pcm_stride, int n_frames,
                          int preload, bool fc_from_frames)
 {
-    LpcnSampleArgs a = b->e->sargs;
+    LpcnSampleArgs a = (b->e->fast && b->e->has_fast_image) ? b->e->sargs_fast : b->e->sargs;
     a.n_streams = b->n; a.n_frames = n_frames; a.preload = preload; a.frame_len = b->frame_len;
     a.fc_advance = fc_from_frames ? 1 : 0;
     a.cond_a = b->d_cond_a; a.cond_b = b->d_cond_b; a.lpc = b->d_lpc;
@@ -488,11 +516,12 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
     const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0;
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);
+    const int nwv = cur_nw_variant(b->e);
     int lds = 0, rc = 0;
     switch (b->S) {
-    case 1: lds = lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(b->e->nw_variant, i8, fast, grid, lds, st, b->d_args); break;
-    case 2: lds = lpcn::Lds<2>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s2(b->e->nw_variant, i8, fast, grid, lds, st, b->d_args); break;
-    default: lds = lpcn::Lds<4>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s4(b->e->nw_variant, i8, fast, grid, lds, st, b->d_args); break;
+    case 1: lds = lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(nwv, i8, fast, grid, lds, st, b->d_args); break;
+    case 2: lds = lpcn::Lds<2>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s2(nwv, i8, fast, grid, lds, st, b->d_args); break;
+    default: lds = lpcn::Lds<4>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s4(nwv, i8, fast, grid, lds, st, b->d_args); break;
     }
     if (rc) { snprintf(g_err, sizeof(g_err), "sample kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return LPCN_E_HIP; }
     return 0;

@@ -40,6 +40,7 @@ extern "C" {
 #define LPCN_WAVES      8
 #define LPCN_MAX_SLOTS  3
 #define LPCN_EARLY_MAX  24     /* most items of a candidate slot that waves 4..7 may compute one sample ahead (float blobs) */
+#define LPCN_DEAL_EH_FAST_I8 0 /* head length of the FAST arithmetic's own image of int8 blobs (model_pack.c: lpcn_model_pack_fast) */
 
 typedef struct lpcn_model_host {
     int is_int8;                 /* blob flavour: 0 = float qweights (DISABLE_DOT_PROD), 1 = int8 (DOT_PROD)  */
@@ -84,6 +85,7 @@ typedef struct lpcn_model_host {
  * malformed / incomplete blob (same condition under which lpcnet_load_model returns -1). */
 int  lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len);
 void lpcn_model_release(lpcn_model_host *m);
+int  lpcn_model_pack_fast(const lpcn_model_host *m, lpcn_model_host *f);   /* 1: FAST shares PARITY's image; 0: f holds FAST's own GRU-A packing */
 /* re-expand the packings and compare them with the blob (0 = consistent) */
 int  lpcn_model_selftest(const lpcn_model_host *m);
 

@@ -92,6 +92,7 @@ static int cmp_group_desc(const void *a, const void *b)
  * (constants from the in-kernel phase clocks, profiles/r03_phase_clocks.txt). */
 typedef struct { int items[LPCN_WAVES], nsl[LPCN_WAVES], nzr[LPCN_WAVES], cand[LPCN_WAVES], zr_items[LPCN_WAVES]; } deal_state;
 static int g_deal_eh = 20;
+static int g_deal_fast = 0;             /* packing the FAST arithmetic's own image (lpcn_model_pack_fast) */
 
 static int deal_head(int w, int cand)
 {
@@ -206,6 +207,10 @@ static int pack_gru_a(lpcn_model_host *m)
     {
         const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (float default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
         g_deal_eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : 20);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
+        if (g_deal_fast) {                                /* FAST int8 (GRU-B split over all waves: no shadow to hide a head in): 0 / 6 / 14 -> 184 / 163 / 167 M */
+            const char *ehf = getenv("LPCN_DEAL_EH_FAST");
+            g_deal_eh = (ehf && *ehf) ? atoi(ehf) : LPCN_DEAL_EH_FAST_I8;
+        }
         if (g_deal_eh < 0) g_deal_eh = 0;
         if (m->is_int8) { g_deal_tg = 4200; g_deal_t0a = 1600; g_deal_t0b = 900; g_deal_ci = 250; g_deal_cu = 220; }
         else            { g_deal_tg = 5000; g_deal_t0a = 1600; g_deal_t0b = 900; g_deal_ci = 395; g_deal_cu = 320; }
@@ -484,6 +489,24 @@ int lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len)
     if (!(m->b_rec = (const float *)blob_need(rec, n, "gru_b_recurrent_weights", q * LPCN_ROWS_B * LPCN_N_B))) return -1;
 
     if (pack_gru_a(m) || pack_gru_b(m)) { lpcn_model_release(m); return -1; }
+    return 0;
+}
+
+/* The FAST arithmetic's own packing of GRU-A (and of the embedding tables, which follow the row assignment): only where its
+ * best dealing differs from PARITY's -- int8 blobs, whose FAST GRU-B leaves no shadow for candidate heads.  `f` becomes a
+ * shallow copy of `m` (blob pointers shared) with its own pk_a_* / pk_emb arrays; returns 1 when no separate image is needed,
+ * 0 on success, -1 on failure.  Release with lpcn_model_release(f) (the GRU-B packing is not copied). */
+int lpcn_model_pack_fast(const lpcn_model_host *m, lpcn_model_host *f)
+{
+    if (!m->is_int8) return 1;                      /* float blobs: head 0 / 8 / 14 / 20 -> 144.8 / 151.1 / 151.3 / 154.3 M: PARITY's dealing is FAST's best too */
+    *f = *m;
+    f->pk_a_w = NULL; f->pk_a_wq = NULL; f->pk_a_blk = NULL; f->pk_a_row = NULL;
+    f->pk_b_w = NULL; f->pk_b_wq = NULL; f->pk_b_start = NULL; f->pk_b_blk = NULL;
+    for (int i = 0; i < 3; i++) f->pk_emb[i] = NULL;
+    g_deal_fast = 1;
+    const int rc = pack_gru_a(f);
+    g_deal_fast = 0;
+    if (rc) { lpcn_model_release(f); return -1; }
     return 0;
 }
 
