@@ -9,6 +9,15 @@ export TMPDIR=/tmp
 RND=${1:-r03}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
+# kernel stats + HBM traffic first: bench.py quotes `roofline.traffic` from profiles/<round>_hbm_traffic*.json, which must have been
+# measured with these very kernel sources (kernel_source_hash)
+for fl in f32 i8; do
+  flag=""; [ $fl = i8 ] && flag="--int8"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
+done
+python tools/profile_summarize.py $RND > /dev/null 2>&1
 timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 timeout 300 python bench.py --int8 > $OUT/bench_i8.json 2> $OUT/bench_i8.err
 timeout 300 python bench.py --streams 1 --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err      # BASELINE config 1
@@ -21,12 +30,6 @@ timeout 600 python bench.py --gpus 2 --share-device --no-cpu-baseline > $OUT/ben
 LPCNET_HIP_NO_SCALAR_GRUB=1 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_f32_lds_state_grub.json 2> /dev/null
 # BASELINE configs 0 -> 1: the reference's own demo on the engine vs its AVX2 builds, one 10-s feature file (wall seconds incl. process start)
 python tools/rtf_demo.py > $OUT/rtf_demo.json 2> $OUT/rtf_demo.err
-for fl in f32 i8; do
-  flag=""; [ $fl = i8 ] && flag="--int8"
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
-done
 python tools/profile_sq.py --tag $RND > $OUT/sq_f32.log 2>&1
 python tools/profile_sq.py --int8 --tag $RND > $OUT/sq_i8.log 2>&1
 # in-kernel s_memtime phase tables (profiling build of the library: LPCN_PROF_MASK=0xFFF python -m lpcnet_amd.build --prof)
