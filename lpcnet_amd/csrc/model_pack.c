@@ -93,10 +93,11 @@ static int cmp_group_desc(const void *a, const void *b)
 typedef struct { int items[LPCN_WAVES], nsl[LPCN_WAVES], nzr[LPCN_WAVES], cand[LPCN_WAVES], zr_items[LPCN_WAVES]; } deal_state;
 static int g_deal_eh = 20;
 static int g_deal_fast = 0;             /* packing the FAST arithmetic's own image (lpcn_model_pack_fast) */
+static int g_deal_hw = LPCN_WAVES / 2;  /* first wave that may carry a candidate head (float: 4 = the waves that never run GRU-B; int8: see pack_gru_a) */
 
 static int deal_head(int w, int cand)
 {
-    if (w < LPCN_WAVES / 2 || cand <= 0) return 0;
+    if (w < g_deal_hw || cand <= 0) return 0;
     const int eh = g_deal_eh < LPCN_EARLY_MAX ? g_deal_eh : LPCN_EARLY_MAX;
     return cand < eh ? cand : eh;
 }
@@ -113,7 +114,7 @@ static long deal_wave_cost(const deal_state *d, int w)
     const long after_gather = g_deal_tg + (long)g_deal_cu * d->zr_items[w];
     long t;
     if (tail >= 10) {
-        t = (w < LPCN_WAVES / 2 ? g_deal_t0a : g_deal_t0b) + (long)g_deal_ci * (tail + d->zr_items[w]);
+        t = (w < g_deal_hw ? g_deal_t0a : g_deal_t0b) + (long)g_deal_ci * (tail + d->zr_items[w]);
         if (t < after_gather) t = after_gather;
     } else {
         t = after_gather + (long)g_deal_cu * tail;
@@ -207,6 +208,14 @@ static int pack_gru_a(lpcn_model_host *m)
     {
         const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (float default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
         g_deal_eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : 20);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
+        {   /* int8 blobs run two streams per workgroup (two workgroups per CU): waves 2 and 3 run no GRU-B there either, and wave 3
+             * takes a head too (at four streams per workgroup it runs it behind GRU-B's gate stage: 141.7 -> 132 M with both,
+             * but the auto-tune does not pick S = 4 for int8 batches of this size) */
+            const char *hw = getenv("LPCN_DEAL_HW");
+            g_deal_hw = (hw && *hw) ? atoi(hw) : (m->is_int8 ? LPCN_DEAL_HW_I8 : LPCN_WAVES / 2);
+            if (g_deal_hw < 2) g_deal_hw = 2;
+            if (g_deal_hw > LPCN_WAVES / 2) g_deal_hw = LPCN_WAVES / 2;
+        }
         if (g_deal_fast) {                                /* FAST int8 (GRU-B split over all waves: no shadow to hide a head in): 0 / 6 / 14 -> 184 / 163 / 167 M */
             const char *ehf = getenv("LPCN_DEAL_EH_FAST");
             g_deal_eh = (ehf && *ehf) ? atoi(ehf) : LPCN_DEAL_EH_FAST_I8;
@@ -304,13 +313,14 @@ static int pack_gru_a(lpcn_model_host *m)
         }
         if (done) {
             /* the lightest GRU-B wave leads the streams (wave 0), the next draws the thresholds (wave 1) */
+            const int nh = g_deal_hw;                 /* (waves without a head: interchangeable) */
             int load4[LPCN_WAVES / 2] = {0}, ord[LPCN_WAVES / 2], newid[LPCN_WAVES];
-            for (int sl = 0; sl < NSLOT; sl++) if (w2[sl] < LPCN_WAVES / 2) load4[w2[sl]] += slot_max[sl];
-            for (int i = 0; i < LPCN_WAVES / 2; i++) ord[i] = i;
-            for (int i = 0; i < LPCN_WAVES / 2; i++)
-                for (int j = i + 1; j < LPCN_WAVES / 2; j++) if (load4[ord[j]] < load4[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+            for (int sl = 0; sl < NSLOT; sl++) if (w2[sl] < nh) load4[w2[sl]] += slot_max[sl];
+            for (int i = 0; i < nh; i++) ord[i] = i;
+            for (int i = 0; i < nh; i++)
+                for (int j = i + 1; j < nh; j++) if (load4[ord[j]] < load4[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
             for (int w = 0; w < LPCN_WAVES; w++) newid[w] = w;
-            for (int i = 0; i < LPCN_WAVES / 2; i++) newid[ord[i]] = i;
+            for (int i = 0; i < nh; i++) newid[ord[i]] = i;
             for (int w = 0; w < LPCN_WAVES; w++) items[w] = 0;
             for (int sl = 0; sl < NSLOT; sl++) { wave_of[sl] = newid[w2[sl]]; items[wave_of[sl]] += slot_max[sl]; }
         }
@@ -614,7 +624,7 @@ int lpcn_model_selftest(const lpcn_model_host *m)
                 seen[row] = 1;
                 if (m->pk_a_allh[wv][k] && row < 2 * LPCN_N_A) { rc = 3; goto done; }
                 const int head = k == 0 ? m->pk_a_head[wv] : 0;       /* slot 0's early items sit end-aligned */
-                if ((wv < LPCN_WAVES / 2 && m->pk_a_head[wv]) || head < 0 || head > LPCN_EARLY_MAX || m->pk_a_bound[wv][LPCN_MAX_SLOTS] + m->pk_a_head[wv] > m->nw) { rc = 7; goto done; }
+                if ((wv < 2 && m->pk_a_head[wv]) || head < 0 || head > LPCN_EARLY_MAX || m->pk_a_bound[wv][LPCN_MAX_SLOTS] + m->pk_a_head[wv] > m->nw) { rc = 7; goto done; }
                 for (int jj = j0 - head; jj < j1; jj++) {
                     const int j = jj < j0 ? m->nw + (jj - j0) : jj;
                     size_t item = ((size_t)wv * m->nw + j) * 64 + lane;

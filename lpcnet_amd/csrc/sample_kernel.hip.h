@@ -1458,9 +1458,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                 }
             }
-            if constexpr (I8 && FAST) {
-                // (FAST int8 splits GRU-B over all waves and its gate waves are 0, GB_W, 2 GB_W, ...: a wave can be both a gate
-                // wave and an early wave -- it computes its candidate heads behind the gate stage)
+            if constexpr (I8) {
+                // (int8 blobs: waves 2 and 3 carry candidate heads too -- at S <= 2 they run no GRU-B -- and FAST splits GRU-B over
+                // all waves with gate waves 0, GB_W, 2 GB_W, ...: a wave can be both a gate wave and an early wave; it computes its
+                // candidate heads behind the gate stage)
                 if (gate_wave && early_wave) run_head();
             }
             LPCN_PROF(11);     // GRU-B gates (gate waves) / early GRU-A slot (the others)
