@@ -88,6 +88,31 @@ def test_packing_roundtrip_other_models(seed, dens):
     assert rc == 0 and info[5] == 0
 
 
+def _layout(blob):
+    out = (C.c_int * 65)()
+    assert api.load_library().lpcnet_hip_model_layout(blob, len(blob), out) == 0
+    o = list(out)
+    waves = [dict(bound=o[1 + w * 7:1 + w * 7 + 4], allh=o[1 + w * 7 + 4:1 + w * 7 + 7], head=o[57 + w]) for w in range(8)]
+    return o[0], waves
+
+
+def test_candidate_heads_sit_where_the_kernel_runs_them(blob_f32, blob_i8):
+    """the dealing of GRU-A (model_pack.c): the head of a wave's candidate chains is stored end-aligned behind its other items
+    (bound[3] + head <= items per lane); float blobs give heads only to the waves that never run GRU-B (4..7), int8 blobs
+    also to wave 3 (two streams per workgroup is their operating point); waves 0 (leader) and 1 (thresholds) never carry one;
+    a head belongs to a candidate-only first slot."""
+    for blob, first in ((blob_f32, 4), (blob_i8, 3)):
+        nw, waves = _layout(blob)
+        assert 1 <= nw <= 64
+        heads = [w["head"] for w in waves]
+        assert all(h == 0 for h in heads[:first]) and all(0 < h <= 24 for h in heads[4:]), heads
+        for w in waves:
+            b = w["bound"]
+            assert b[0] == 0 and b[0] <= b[1] <= b[2] <= b[3] and b[3] + w["head"] <= nw, (w, nw)
+            if w["head"]:
+                assert w["allh"][0] == 1, w
+
+
 def test_no_gpu_means_loud_failure_not_fallback(hip_lib, blob_f32):
     import torch
     if torch.cuda.is_available():
