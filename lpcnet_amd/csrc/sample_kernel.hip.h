@@ -103,6 +103,9 @@ struct LpcnSampleArgs {
 #ifndef LPCN_ENABLE_PROF
 #define LPCN_ENABLE_PROF 0
 #endif
+#ifndef LPCN_PARITY_MFMA
+#define LPCN_PARITY_MFMA 2      // PARITY float items: 1 = matrix pipe as exact multiplier + 16 adds, 2 = + packed adds over stream pairs (S = 4)
+#endif
 #define LPCN_DBG_STRIDE 1600    // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,pred, leader clocks barrier->publish, the tree's own decision; [448..1600) GRU-A pre-activations
 
 namespace lpcn {
@@ -697,6 +700,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
                 hq[j % (PF + 1)] = *(const HT *)(smem + L::hA + off);
             };
+            // (LPCN_PARITY_MFMA == 2) the matrix pipe's addend: four registers of -0.0, re-materialised where an item chain starts so
+            // that they are not live across the other phases
+            typedef float negz_t __attribute__((ext_vector_type(4)));
+            negz_t negz = {-0.f, -0.f, -0.f, -0.f};
+            auto load_negz = [&]() { negz = (negz_t){-0.f, -0.f, -0.f, -0.f}; asm volatile("" : "+v"(negz)); };
+            if constexpr (!I8 && !FAST && S == 4 && LPCN_PARITY_MFMA == 2) load_negz();
             // one item = (this lane's row) x (one 4-wide input block) for all S streams
             auto mac = [&](const int j) {
                 // one item = (this lane's row) x (one 4-wide input block) for all S streams; per output
@@ -745,10 +754,27 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     acc[0] = av[0]; acc[1] = av[1];
                     if constexpr (S == 4) { acc[2] = av[2]; acc[3] = av[3]; }
                 }
-#ifndef LPCN_PARITY_MFMA
-#define LPCN_PARITY_MFMA 0
-#endif
-                if constexpr (!FAST && S >= 2 && LPCN_PARITY_MFMA) {
+                if constexpr (!FAST && S == 4 && LPCN_PARITY_MFMA == 2) {
+                    // the products of a column for all four streams from ONE matrix-pipe instruction (C = -0.0: bit for bit the
+                    // separately rounded product), the sums as two v_pk_add_f32 over stream pairs -- each half of a packed add is
+                    // rounded on its own, so the order of every row's sum is still the reference's: 4 MFMA + 8 packed adds per
+                    // item instead of 16 DPP multiplies + 16 adds
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
+                    // (the four products of an item are issued back to back into four result tuples: hipcc otherwise re-uses one
+                    // tuple and every column waits out the matrix pipe's latency behind s_nop)
+                    f4 pv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pv[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(hk[c], wk[c], negz, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        a01 = a01 + __builtin_shufflevector(pv[c], pv[c], 0, 1);
+                        a23 = a23 + __builtin_shufflevector(pv[c], pv[c], 2, 3);
+                    }
+                    acc[0] = a01[0]; acc[1] = a01[1]; acc[2] = a23[0]; acc[3] = a23[1];
+                } else if constexpr (!FAST && S >= 2 && LPCN_PARITY_MFMA) {
                     // PARITY: the same instruction as a MULTIPLIER -- with C = -0.0 the fused result is the separately rounded
                     // product bit for bit (x + (-0) = x, also for zeros), one instruction instead of the four DPP multiplies of a
                     // column; the sums stay ordinary adds in the reference's order.
@@ -852,6 +878,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_REMAT_S(jstar);
             // The early head of slot 0 (see `hl`): one compile-time chain over the last LPCN_EARLY_MAX items, entered at NW - hl.
             auto run_head = [&]() __attribute__((always_inline)) {
+                if constexpr (!I8 && !FAST && S == 4 && LPCN_PARITY_MFMA == 2) load_negz();
                 {
                     int r = row[0];
                     LPCN_REMAT_V(r);

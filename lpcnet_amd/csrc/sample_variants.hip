@@ -36,6 +36,10 @@ static int launch(int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_arg
 template <bool FAST>
 static int pick(int nw, int is_int8, int pack2, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args)
 {
+#ifdef LPCN_ONLY_BENCH_VARIANT       // tools: compile only the benchmark model's PARITY float kernel (quick assembly listings)
+    if constexpr (FAST) return (int)hipErrorInvalidValue;
+    else return (!is_int8 && nw == 30) ? launch<30, false, false>(grid, lds, st, d_args) : (int)hipErrorInvalidValue;
+#else
     if (is_int8) {
         switch (nw) {
         case 32: return (pack2 && LPCN_S <= 2) ? launch<32, true, FAST, (LPCN_S <= 2)>(grid, lds, st, d_args) : launch<32, true, FAST>(grid, lds, st, d_args);
@@ -51,6 +55,7 @@ static int pick(int nw, int is_int8, int pack2, int grid, int lds, hipStream_t s
     case 36: return launch<36, false, FAST>(grid, lds, st, d_args);
     default: return launch<40, false, FAST>(grid, lds, st, d_args);
     }
+#endif
 }
 
 // returns a hipError_t value (0 = launched)
