@@ -384,7 +384,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
     const bool b_dense = Ap->b_dense != 0;
     // PARITY, float blob, dense GRU-B input matrix: GRU-B takes the GRU-A state through scalar loads (see grub_scalar_loop.inc)
-    const bool gb_scalar = !I8 && !FAST && b_dense && Ap->hmir != nullptr;
+#ifndef LPCN_GRUB_LDS
+#define LPCN_GRUB_LDS 1         // 1: PARITY float GRU-B reads the state from LDS as a broadcast (grub_lds_loop_s*.inc) instead of the L2 mirror + SGPRs
+#endif
+    const bool gb_lds = LPCN_GRUB_LDS && !I8 && !FAST && b_dense;
+    const bool gb_scalar = !LPCN_GRUB_LDS && !I8 && !FAST && b_dense && Ap->hmir != nullptr;
     // Argument-block members the sample loop needs on its critical path, fetched ONCE and made opaque: left to itself the
     // compiler re-reads them with a scalar load at every use (cheaper than keeping an SGPR, it thinks), and a scalar load in
     // flight forces every LDS wait behind it to lgkmcnt(0) -- right behind a barrier that is a stall for every wave (int8:
@@ -452,6 +456,16 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 if (b_dense && i < nb_b * BW_DW) {
                     const int blk_abs = i >> 5, ri = (i >> 2) & 7, c = i & 3;
                     di = ((((blk_abs / 96) * 2 + (ri >> 2)) * 96 + blk_abs % 96) * 4 + (ri & 3)) * 4 + c;
+                }
+            }
+            if constexpr (!FAST && !I8) {
+                // gb_lds: a wave's weight read fetches 16 B per row from six row groups 12 288 B apart -- the same 32 banks for
+                // every group, a two-way conflict inside each 16-lane service group of ds_read_b128.  Row groups 2, 3 and 5 are
+                // shifted by one more block (128 B = the other half of the banks); the pad blocks behind the matrix absorb it.
+                if (gb_lds) {
+                    if (i < nb_b * BW_DW) di = i + ((0x321100 >> (4 * ((i >> 5) / 96))) & 15) * 32;
+                    else if (i < (nb_b + 5) * BW_DW) di = i + 3 * 32;     // zero blocks behind the shifted last group
+                    else continue;
                 }
             }
             ((uint32_t *)(smem + L::bw))[di] = i < nb_b * BW_DW ? ((const LPCN_GLOBAL uint32_t *)bw)[i] : 0u;
@@ -1389,6 +1403,25 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     for (int j = 0; j < NB; ++j) rec = __builtin_fmaf(sm_brec[j * RB + r], sm_hB[s * NB + j], rec);
                     zrh = zrh + gb_part_fast(s, 0, gb_qa);
                     (void)g; (void)ri;
+                } else if (gb_lds) {
+                    // state as a broadcast LDS read per block, weights as before: one hand-scheduled assembly block (tools/gen_grub_asm.py --lds S)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
+                    uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::bw + (sm_bstart[g] * 8 + ri) * 16 + ((0x321100 >> (4 * g)) & 15) * 128);
+                    uint32_t hp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::hA + s * 16);
+                    if constexpr (S == 4) {
+                        asm volatile(
+#include "grub_lds_loop_s4.inc"
+                            : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
+                    } else if constexpr (S == 2) {
+                        asm volatile(
+#include "grub_lds_loop_s2.inc"
+                            : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
+                    } else {
+                        asm volatile(
+#include "grub_lds_loop_s1.inc"
+                            : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
+                    }
                 } else if (gb_scalar) {
                     // state through SGPRs: the whole 96-block loop is one hand-scheduled assembly block (tools/gen_grub_asm.py)
                     // (a ring of 8 sample slots with one s_dcache_inv per turn instead of one per sample was measured: 102.7 vs 104.9 M --

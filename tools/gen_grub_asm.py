@@ -113,5 +113,52 @@ def main():
         print('"%s\\n\\t"' % ln)
 
 
+def main_lds(S):
+    """GRU-B input mat-vec with the state operand read from LDS as a BROADCAST (every lane the same 16 bytes: block b of the
+    wave's stream) -- no L2 mirror, no scalar cache: the state a GRU-B wave needs is the one the gate stage has just written
+    to LDS for GRU-A's items.  Two ds_read_b128 per block (the lane's weights + the state block), ring of 4 blocks each,
+    products of block b+1 formed during the adds of block b.  LDS returns in order, so the waits are exact counts.
+    Layout of the state: [block][stream][4] floats, 16 B pad every 4 blocks (Lds<S>::ha_off)."""
+    stride = 16 * S
+    ha_off = lambda p: p * stride + (p >> 2) * 16
+    WR = [224, 228, 232, 236]      # weight ring (float4 per block)
+    HR = [240, 244, 248, 252]      # state ring
+    PS = [216, 220]                # product sets
+    CNT = 70
+    BPT = 16                       # blocks per trip
+    lines = []
+    rdw = lambda slot, blk: f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}"
+    rdh = lambda slot, blk: f"ds_read_b128 v[{HR[slot]}:{HR[slot] + 3}], %[hp] offset:{ha_off(blk)}"
+    prod = lambda pset, slot: [f"v_pk_mul_f32 v[{PS[pset]}:{PS[pset] + 1}], v[{HR[slot]}:{HR[slot] + 1}], v[{WR[slot]}:{WR[slot] + 1}]",
+                               f"v_pk_mul_f32 v[{PS[pset] + 2}:{PS[pset] + 3}], v[{HR[slot] + 2}:{HR[slot] + 3}], v[{WR[slot] + 2}:{WR[slot] + 3}]"]
+    lines += [f"s_mov_b32 s{CNT}, {96 // BPT}"]
+    for b in range(3):
+        lines += [rdw(b, b), rdh(b, b)]
+    lines += ["s_waitcnt lgkmcnt(4)"] + prod(0, 0)
+    lines += [".p2align 4"] + ["s_nop 0"] * PHASE
+    lines += ["1:"]
+    for k in range(BPT):
+        pr = prod((k + 1) & 1, (k + 1) & 3)
+        a = [f"v_add_f32 %[z], %[z], v{PS[k & 1] + j}" for j in range(4)]
+        lines += [rdw((k + 3) & 3, k + 3), rdh((k + 3) & 3, k + 3), "s_waitcnt lgkmcnt(4)",
+                  a[0], pr[0], a[1], pr[1], a[2], a[3]]
+    lines += [f"v_add_u32 %[wp], {BPT * 128}, %[wp]",
+              f"v_add_u32 %[hp], {ha_off(BPT)}, %[hp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py --lds %d -- do not edit" % S)
+    print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of the stream's state, block 0 (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"v{i}" for i in range(216, 256)]
+    print("#undef LPCN_GRUB_LDS_CLOBBERS")
+    print("#define LPCN_GRUB_LDS_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
 if __name__ == "__main__":
-    main()
+    if "--lds" in sys.argv:
+        main_lds(int(sys.argv[sys.argv.index("--lds") + 1]))
+    else:
+        main()
