@@ -40,6 +40,7 @@ extern "C" {
 #define LPCN_WAVES      8
 #define LPCN_MAX_SLOTS  3
 #define LPCN_EARLY_MAX  24     /* most items of a candidate slot that waves 4..7 may compute one sample ahead (float blobs) */
+#define LPCN_DEAL_EH_F32 24    /* float blobs: head length of the early candidate items (round 4, matrix-pipe items: 20 / 22 / 24 -> 121.3 / 123.5 / 123.9 M samples/s) */
 #define LPCN_DEAL_HW_I8 3      /* int8 blobs: first wave that may carry a candidate head (model_pack.c; 4 / 3 / 2 -> 153.4 / 156.2 / 154.1 M samples/s) */
 #define LPCN_DEAL_EH_FAST_I8 0 /* head length of the FAST arithmetic's own image of int8 blobs (model_pack.c: lpcn_model_pack_fast) */
 

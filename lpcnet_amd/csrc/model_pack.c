@@ -207,7 +207,7 @@ static int pack_gru_a(lpcn_model_host *m)
     const int deal2 = !m->is_int8 || !(old_i8 && old_i8[0] == '1');      /* split candidate chains (see deal_wave_cost) */
     {
         const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (float default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
-        g_deal_eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : 20);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
+        g_deal_eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : LPCN_DEAL_EH_F32);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
         {   /* int8 blobs run two streams per workgroup (two workgroups per CU): waves 2 and 3 run no GRU-B there either, and wave 3
              * takes a head too (at four streams per workgroup it runs it behind GRU-B's gate stage: 141.7 -> 132 M with both,
              * but the auto-tune does not pick S = 4 for int8 batches of this size) */

@@ -27,6 +27,7 @@ P = {0: 248, 1: 252}   # product registers (alternate per block)
 OFF, OFFC, CNT, DUMMY = 68, 69, 70, 71
 import sys
 PHASE = int(sys.argv[sys.argv.index("--phase") + 1]) if "--phase" in sys.argv else 0
+MASK48 = "--mask48" in sys.argv
 
 
 def pk_mul(dst, sreg, vreg):
@@ -132,6 +133,8 @@ def main_lds(S):
     prod = lambda pset, slot: [f"v_pk_mul_f32 v[{PS[pset]}:{PS[pset] + 1}], v[{HR[slot]}:{HR[slot] + 1}], v[{WR[slot]}:{WR[slot] + 1}]",
                                f"v_pk_mul_f32 v[{PS[pset] + 2}:{PS[pset] + 3}], v[{HR[slot] + 2}:{HR[slot] + 3}], v[{WR[slot] + 2}:{WR[slot] + 3}]"]
     lines += [f"s_mov_b32 s{CNT}, {96 // BPT}"]
+    if MASK48:          # only the 48 row lanes take part: a quarter less LDS return traffic per read
+        lines += ["s_mov_b64 s[72:73], exec", "s_bfm_b64 exec, 48, 0"]
     for b in range(3):
         lines += [rdw(b, b), rdh(b, b)]
     lines += ["s_waitcnt lgkmcnt(4)"] + prod(0, 0)
@@ -148,9 +151,11 @@ def main_lds(S):
               f"s_cmp_lg_u32 s{CNT}, 0",
               "s_cbranch_scc1 1b",
               "s_waitcnt lgkmcnt(0)"]
+    if MASK48:
+        lines += ["s_mov_b64 exec, s[72:73]"]
     print("// generated by tools/gen_grub_asm.py --lds %d -- do not edit" % S)
     print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of the stream's state, block 0 (in/out VGPR)")
-    clob = [f"s{CNT}"] + [f"v{i}" for i in range(216, 256)]
+    clob = [f"s{CNT}"] + (["s72", "s73"] if MASK48 else []) + [f"v{i}" for i in range(216, 256)]
     print("#undef LPCN_GRUB_LDS_CLOBBERS")
     print("#define LPCN_GRUB_LDS_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
     for ln in lines:
