@@ -28,6 +28,7 @@ OFF, OFFC, CNT, DUMMY = 68, 69, 70, 71
 import sys
 PHASE = int(sys.argv[sys.argv.index("--phase") + 1]) if "--phase" in sys.argv else 0
 MASK48 = "--mask48" in sys.argv
+POLL = "--poll" in sys.argv
 
 
 def pk_mul(dst, sreg, vreg):
@@ -143,8 +144,20 @@ def main_lds(S):
     for k in range(BPT):
         pr = prod((k + 1) & 1, (k + 1) & 3)
         a = [f"v_add_f32 %[z], %[z], v{PS[k & 1] + j}" for j in range(4)]
-        lines += [rdw((k + 3) & 3, k + 3), rdh((k + 3) & 3, k + 3), "s_waitcnt lgkmcnt(4)",
-                  a[0], pr[0], a[1], pr[1], a[2], a[3]]
+        if POLL and k == 13:
+            # the reads from here on reach into the NEXT range of 16 blocks: its ready counter (sampled at block 5 of this trip, long
+            # returned: LDS completes in order) must have reached `want`; otherwise spin on it (rare: the gate stage produces a range
+            # faster than this loop consumes one)
+            lines += ["v_readfirstlane_b32 s74, v215", "s_cmp_ge_i32 s74, %[want]", "s_cbranch_scc1 3f",
+                      "2:", "s_sleep 1", "ds_read_b32 v215, %[cp]", "s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 s74, v215",
+                      "s_cmp_ge_i32 s74, %[want]", "s_cbranch_scc0 2b", "3:"]
+        lines += [rdw((k + 3) & 3, k + 3), rdh((k + 3) & 3, k + 3)]
+        if POLL and k == 5:
+            lines += ["ds_read_b32 v215, %[cp]"]
+        # (one more LDS operation in flight behind block 5's reads until it has returned: the counts stay upper bounds of what must be done)
+        lines += ["s_waitcnt lgkmcnt(%d)" % (5 if POLL and k == 5 else 4), a[0], pr[0], a[1], pr[1], a[2], a[3]]
+    if POLL:
+        lines += ["v_add_u32 %[cp], 4, %[cp]"]
     lines += [f"v_add_u32 %[wp], {BPT * 128}, %[wp]",
               f"v_add_u32 %[hp], {ha_off(BPT)}, %[hp]",
               f"s_sub_u32 s{CNT}, s{CNT}, 1",
@@ -155,9 +168,12 @@ def main_lds(S):
         lines += ["s_mov_b64 exec, s[72:73]"]
     print("// generated by tools/gen_grub_asm.py --lds %d -- do not edit" % S)
     print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of the stream's state, block 0 (in/out VGPR)")
-    clob = [f"s{CNT}"] + (["s72", "s73"] if MASK48 else []) + [f"v{i}" for i in range(216, 256)]
-    print("#undef LPCN_GRUB_LDS_CLOBBERS")
-    print("#define LPCN_GRUB_LDS_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    clob = [f"s{CNT}"] + (["s72", "s73"] if MASK48 else []) + (["s74", "v215"] if POLL else []) + [f"v{i}" for i in range(216, 256)]
+    name = "LPCN_GRUB_LDSP_CLOBBERS" if POLL else "LPCN_GRUB_LDS_CLOBBERS"
+    if POLL:
+        print("// + %[cp] LDS byte address of the ready counter of block range 1 (in/out VGPR; one i32 per range of 16 blocks, two always-ready words behind the last), %[want] value a ready counter has reached (SGPR)")
+    print("#undef " + name)
+    print("#define " + name + " " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
     for ln in lines:
         print('"%s\\n\\t"' % ln)
 
