@@ -518,14 +518,10 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);
     const int nwv = cur_nw_variant(b->e);
     int lds = 0, rc = 0;
-    // (the PARITY kernels of float blobs use the TREE2 layout of LDS: see Lds<S, T2>)
-    const bool par_f = !b->e->is_int8 && !b->e->fast;                             // PARITY kernels of float blobs: TREE2 at S <= 2 (see Lds<S, T2, FCT>)
-    const bool t2 = par_f && LPCN_TREE2 && (b->S <= 2 || LPCN_TREE2 > 1), l2c = par_f && ((t2 && b->S == 4) || LPCN_L2_COND);
     switch (b->S) {
-    case 1: lds = t2 ? lpcn::Lds<1, false, true>::total(b->e->nb_b, false) : lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(nwv, i8, fast, grid, lds, st, b->d_args); break;
-    case 2: lds = t2 ? lpcn::Lds<2, false, true>::total(b->e->nb_b, false) : lpcn::Lds<2>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s2(nwv, i8, fast, grid, lds, st, b->d_args); break;
-    default: lds = l2c ? (t2 ? lpcn::Lds<4, true, true>::total(b->e->nb_b, false) : lpcn::Lds<4, true, false>::total(b->e->nb_b, false)) : lpcn::Lds<4>::total(b->e->nb_b, b->e->is_int8);
-             rc = lpcn_launch_sample_s4(nwv, i8, fast, grid, lds, st, b->d_args); break;
+    case 1: lds = lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(nwv, i8, fast, grid, lds, st, b->d_args); break;
+    case 2: lds = lpcn::Lds<2>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s2(nwv, i8, fast, grid, lds, st, b->d_args); break;
+    default: lds = lpcn::Lds<4>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s4(nwv, i8, fast, grid, lds, st, b->d_args); break;
     }
     if (rc) { snprintf(g_err, sizeof(g_err), "sample kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return LPCN_E_HIP; }
     return 0;

@@ -103,12 +103,6 @@ struct LpcnSampleArgs {
 #ifndef LPCN_ENABLE_PROF
 #define LPCN_ENABLE_PROF 0
 #endif
-#ifndef LPCN_L2_COND
-#define LPCN_L2_COND 0          // tools: the T2 layout's L2-resident frame conditioning / {bias, diag} without the TREE2 schedule
-#endif
-#ifndef LPCN_TREE2
-#define LPCN_TREE2 1            // PARITY float: a stream's GRU-B wave also runs its tree (two rounds of four levels) and its leader work -- no barrier behind the gate stage
-#endif
 #ifndef LPCN_PARITY_MFMA
 #define LPCN_PARITY_MFMA 2      // PARITY float items: 1 = matrix pipe as exact multiplier + 16 adds, 2 = + packed adds over stream pairs (S = 4)
 #endif
@@ -134,28 +128,23 @@ template <typename T> __device__ __forceinline__ LPCN_GLOBAL T *as_global_rw(T *
 #define LPCN_REMAT_S(x) asm volatile("" : "+s"(x))
 
 // ---- LDS carve-up (bytes), all offsets multiples of 16 ---------------------------------------
-// T2 (the TREE2 kernels: PARITY, float blobs): the dual-FC tables live in LDS; the frame conditioning of GRU-A and the rows'
-// {bias, diag} pairs do not -- those are read from L2 while a wave waits for the leader anyway, and their 27.6 KB are what
-// makes room for the tables next to 75 KB of GRU-B weights
-template <int S, bool T2 = false, bool FCT = T2> struct Lds {
+template <int S> struct Lds {
     static constexpr int HA_STRIDE = 16 * S;                       // bytes per 4-neuron block
     static constexpr int hA     = 0;
     static constexpr int hA_sz  = 96 * HA_STRIDE + 24 * 16;         // 16 B pad every 4 blocks
     static constexpr int pre    = hA + hA_sz;                       // [S][1152] f32 pre-activations
     static constexpr int inh    = pre + S * RA * 4;                 // [S][384]  input part of candidate rows
     static constexpr int cond   = inh + S * NA * 4;                 // [S][1152] frame conditioning (GRU-A)
-    static constexpr int abias  = cond + (T2 ? 0 : S * RA * 4);     // [1152]{bias, diag}: recurrent bias and diagonal weight per row
-    static constexpr int adiag  = abias + (T2 ? 0 : RA * 4);        // (second half of the interleaved {bias, diag} table)
-    static constexpr int hT     = adiag + (T2 ? 0 : RA * 4);        // [384][S] second copy of the GRU-A state, stream-interleaved
+    static constexpr int abias  = cond + S * RA * 4;                // [1152]{bias, diag}: recurrent bias and diagonal weight per row
+    static constexpr int adiag  = abias + RA * 4;                   // (second half of the interleaved {bias, diag} table)
+    static constexpr int hT     = adiag + RA * 4;                   // [384][S] second copy of the GRU-A state, stream-interleaved
     static constexpr int hB     = hT + NA * S * 4;                  // [S][16]
     static constexpr int idx    = hB + S * NB * 4;                  // [S][4] i32 (sig,pred,exc,live)
     static constexpr int thr    = idx + S * 16;                     // [S][8] f32
     static constexpr int mask   = thr + S * 32;                     // [S][8] u64
     static constexpr int lead   = mask + S * 64;                    // [S][8] leader scalars (pred,deemph,exc,head,rng4)
     static constexpr int flag   = lead + S * 32;                    // [4] i32: sequence number of the newest published sample indices
-    static constexpr int gcnt   = flag + 16;                        // [8] i32: arrivals per range of 16 state blocks (streamed gate stage); [6], [7] always ready
-    static constexpr int pflag  = gcnt + 32;                        // [4] i32: per stream, sequence number of its newest published indices (TREE2)
-    static constexpr int condb  = pflag + 16;                       // [S][48] f32
+    static constexpr int condb  = flag + 16;                        // [S][48] f32
     static constexpr int lpc    = condb + S * RB * 4;               // [S][16] f32
     static constexpr int sig    = lpc + S * 64;                     // [S][16] f32 ring of past samples
     static constexpr int pcmbuf = sig + S * 64;                     // [S][160] i16
@@ -169,11 +158,7 @@ template <int S, bool T2 = false, bool FCT = T2> struct Lds {
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
     static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
     static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 16 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
-    // float blobs: the dual-FC tables behind everything else (TREE2: the tree's second round fetches rows that depend on the first)
-    static constexpr int fcw(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }                            // [256][2][16] f32
-    static constexpr int fcb(int nb_b, bool i8) { return fcw(nb_b, i8) + 256 * 2 * 16 * 4; }                  // [2][256]
-    static constexpr int fcf(int nb_b, bool i8) { return fcb(nb_b, i8) + 2 * 256 * 4; }                       // [2][256]
-    static constexpr int total(int nb_b, bool i8) { return FCT ? fcf(nb_b, i8) + 2 * 256 * 4 : hBh(nb_b, i8) + S * 32; }   // (bw pad: the GRU-B pipeline reads ahead)
+    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }                          // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
     static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
     static constexpr int xqT    = hA + 384 * S;                     // [S][96] dwords: the same, stream-major (GRU-B input)
@@ -321,14 +306,7 @@ template <bool FAST> __device__ __forceinline__ float act_sigmoid(const float x,
 template <int S, int NW, bool I8, bool FAST, bool PACK2 = false>
 __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(const LpcnSampleArgs *__restrict__ Ap)
 {
-    // TREE2: from the gate stage on, stream s lives on wave s alone: GRU-B, GRU-B's gates, the sampling tree -- evaluated in two
-    // rounds of four levels (15 nodes x 2 channels = 30 lanes per round; the second round's rows depend on the first round's
-    // decisions, the walk itself is scalar code on the ballot) instead of all 255 nodes on all eight waves -- the LPC
-    // predictor and the mu-law indices of the next sample, published through a per-stream flag.  The sample step keeps two
-    // workgroup barriers (behind GRU-A's rows and behind its gates) instead of four.
-    constexpr bool TREE2 = LPCN_TREE2 && !I8 && !FAST && (S <= 2 || LPCN_TREE2 > 1);
-    constexpr bool L2C = (TREE2 && S == 4) || (LPCN_L2_COND && !I8 && !FAST);
-    using L = Lds<S, L2C, TREE2>;
+    using L = Lds<S>;
     using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
     using HT = typename std::conditional<I8, typename XVec<S>::type, float4>::type;   // one fetched state block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -410,15 +388,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #define LPCN_GRUB_LDS 1         // 1: PARITY float GRU-B reads the state from LDS as a broadcast (grub_lds_loop_s*.inc) instead of the L2 mirror + SGPRs
 #endif
     const bool gb_lds = LPCN_GRUB_LDS && !I8 && !FAST && b_dense;
-#ifndef LPCN_STREAM_GATES
-#define LPCN_STREAM_GATES 0     // (measured: no gain) S = 4, gb_lds: the gate stage hands the new GRU-A state to GRU-B in ranges of 16 blocks, GRU-B waves leave it after the first
-#endif
-    // Streamed gate stage (PARITY float, dense GRU-B, four streams): GRU-B consumes the new state in block order at ~65 clk per
-    // block, the gate stage produces all of it in ~2 k clk -- so the GRU-B waves compute only the first 16 blocks' neurons (one
-    // item per lane), the other four waves the remaining five ranges in order, every range is announced through its own LDS
-    // arrival counter, and a GRU-B wave starts as soon as ranges 0 and 1 are there (grub_lds_poll_loop_s4.inc checks the later
-    // ones on its way).  No workgroup barrier between the gate stage and GRU-B.
-    const bool stream_gates = LPCN_STREAM_GATES && S == 4 && gb_lds;
     const bool gb_scalar = !LPCN_GRUB_LDS && !I8 && !FAST && b_dense && Ap->hmir != nullptr;
     // Argument-block members the sample loop needs on its critical path, fetched ONCE and made opaque: left to itself the
     // compiler re-reads them with a scalar load at every use (cheaper than keeping an SGPR, it thinks), and a scalar load in
@@ -463,11 +432,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             ((float *)(smem + L::logit))[i] = t2[i];
         }
         const auto *ab1 = as_global(Ap->a_bias1), *adg = as_global(Ap->a_diag);
-        if constexpr (!L2C) {
         for (int i = tid; i < RA; i += LPCN_WG_THREADS) {
             ((float *)(smem + L::abias))[2 * i] = ab1[i];          // [row]{bias, diag}: one 8-byte read per row
             ((float *)(smem + L::abias))[2 * i + 1] = adg[i];
-        }
         }
         const auto *br = as_global(Ap->b_rec), *bb = as_global(Ap->b_bias);
         for (int i = tid; i < (I8 ? RB * 4 : NB * RB); i += LPCN_WG_THREADS) ((uint32_t *)(smem + L::brec))[i] = ((const LPCN_GLOBAL uint32_t *)br)[i];   // bit copy (dwords of 4 int8 for I8)
@@ -502,14 +469,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
             }
             ((uint32_t *)(smem + L::bw))[di] = i < nb_b * BW_DW ? ((const LPCN_GLOBAL uint32_t *)bw)[i] : 0u;
-        }
-        if constexpr (TREE2) {
-            const auto *fw = as_global(Ap->fc_w), *fb = as_global(Ap->fc_b), *ff = as_global(Ap->fc_f);
-            for (int i = tid; i < 256 * 2 * NB; i += LPCN_WG_THREADS) ((float *)(smem + L::fcw(nb_b, I8)))[i] = fw[i];
-            for (int i = tid; i < 2 * 256; i += LPCN_WG_THREADS) {
-                ((float *)(smem + L::fcb(nb_b, I8)))[i] = fb[i];
-                ((float *)(smem + L::fcf(nb_b, I8)))[i] = ff[i];
-            }
         }
         for (int i = tid; i < S * NA; i += LPCN_WG_THREADS) {
             const int s = i / NA, n = i % NA;
@@ -550,11 +509,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // src/lpcnet.c:252-263) and, per frame, LPC coefficient j.
     // (lrow/tap are recomputed from the thread id and the coefficient re-read from LDS where needed: every
     // VGPR that stays live across the GRU-A item loop costs the fp32 engine a spill)
-    // (TREE2: the leader lanes of stream s are lanes 0..15 of wave s)
-#define LPCN_IS_LEADER (TREE2 ? ((tid0 >> 6) < S && (tid0 & 63) < 16) : tid0 < 16 * S)
-#define LPCN_LROW (TREE2 ? (tid0 >> 6) : ((tid0 & 63) >> 4))
+#define LPCN_LROW ((tid0 & 63) >> 4)
 #define LPCN_TAP (tid0 & 15)
-    float hist = LPCN_IS_LEADER ? states[stream_of(LPCN_LROW)].last_sig[LPCN_TAP] : 0.f;
+    float hist = (tid0 < 16 * S) ? states[stream_of(LPCN_LROW)].last_sig[LPCN_TAP] : 0.f;
     auto row_shr1 = [](float v, float fill) {               // value of the previous lane of the 16-lane row; lane 0 gets `fill`
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
     };
@@ -562,7 +519,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     auto open_sample = [&](const bool live, const float newest, const float prod, const int exc, const bool per_frame) {   // wave 0, lanes < 16*S
         int t_ = tid0;
         LPCN_REMAT_V(t_);
-        const int lrow = TREE2 ? (t_ >> 6) : (t_ & 63) >> 4, tap = t_ & 15;
+        const int lrow = (t_ & 63) >> 4, tap = t_ & 15;
         // pred = ((0 - s0*a0) - s1*a1) - ... in tap order (src/lpcnet.c:252): every lane of the row runs the whole chain,
         // taking product j from lane j of its row through a DPP row broadcast folded into the subtract -- the
         // broadcast operand does not depend on the chain, so the 16 steps cost only the add latency
@@ -601,30 +558,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // candidate-only slot of waves 4..7 last, so the rest of the sample simply ends at item bound[2].)
     bool head_ready = false;                                 // wave-uniform: the parked partial sums belong to the sample about to start
     const uint32_t flag_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::flag);
-    const uint32_t pflag_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::pflag);
     auto publish_indices = [&]() {                           // after the sm_idx writes of the same lane
-        if constexpr (TREE2) {
-            const uint32_t a = pflag_addr + 4u * (uint32_t)LPCN_LROW;
-            asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(seq) : "memory");
-        } else {
-            asm volatile("ds_write_b32 %0, %1" :: "v"(flag_addr), "v"(seq) : "memory");
-        }
+        asm volatile("ds_write_b32 %0, %1" :: "v"(flag_addr), "v"(seq) : "memory");
     };
     auto wait_indices = [&]() {
-        if constexpr (TREE2) {                               // every stream's leader has published this sample's indices
-            int ok;
-            do {
-                typename XVec<S>::type v;
-                if constexpr (S == 4) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pflag_addr) : "memory");
-                else if constexpr (S == 2) asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pflag_addr) : "memory");
-                else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pflag_addr) : "memory");
-                if constexpr (S == 1) ok = v == seq;
-                else { ok = 1; for (int q = 0; q < S; ++q) ok &= (v[q] == seq) ? 1 : 0; }
-                ok = __builtin_amdgcn_readfirstlane(ok);
-                if (!ok) __builtin_amdgcn_s_sleep(1);
-            } while (!ok);
-            return;
-        }
         int v;
         do {
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
@@ -658,35 +595,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                      "s_mov_b64 exec, %0"
                      : "=&s"(ex) : "v"(arrive_addr), "v"(one) : "memory");
     };
-    // streamed gate stage: arrival counters per range of 16 state blocks (L::gcnt), `gbseq` samples handed off so far
-    const uint32_t gcnt_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::gcnt);
-    auto range_arrive = [&](const int r) {                   // behind this wave's LDS stores of the range (a wave's LDS operations complete in order)
-        int one = 1;
-        unsigned long long ex;
-        const uint32_t a = gcnt_addr + 4u * (uint32_t)r;
-        asm volatile("s_mov_b64 %0, exec\n\t"
-                     "s_mov_b64 exec, 1\n\t"
-                     "ds_add_u32 %1, %2\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(ex) : "v"(a), "v"(one) : "memory");
-    };
-    auto ranges_wait = [&](const int upto) {                 // ranges [0, upto) have all four arrivals of this sample
-        typedef int i4 __attribute__((ext_vector_type(4)));
-        const int want = gbseq * (LPCN_WAVES / 2);
-        int m;
-        do {
-            i4 lo, hi;
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(gcnt_addr) : "memory");
-            m = lo[0] < lo[1] ? lo[0] : lo[1];
-            if (upto > 2) {
-                const int m1 = lo[2] < lo[3] ? lo[2] : lo[3], m2 = hi[0] < hi[1] ? hi[0] : hi[1];
-                m = m < m1 ? m : m1;
-                m = m < m2 ? m : m2;
-            }
-            m = __builtin_amdgcn_readfirstlane(m);
-            if (m < want) __builtin_amdgcn_s_sleep(1);
-        } while (m < want);
-    };
     auto mirror_wait = [&]() {
         int v;
         const int want = gbseq * LPCN_WAVES;
@@ -697,8 +605,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         } while (v != want);
     };
     if (tid0 == 0) { *(int *)(smem + L::flag) = 0; *(int *)(smem + L::flag + 4) = 0; }
-    if (tid0 < 8) ((int *)(smem + L::gcnt))[tid0] = tid0 < 6 ? 0 : 0x7FFFFFFF;
-    if (tid0 < 4) ((int *)(smem + L::pflag))[tid0] = 0;
 
 #if LPCN_ENABLE_PROF      // per-phase shader-clock accounting (profiling builds only: it costs VGPRs)
     unsigned long long *const prof = Ap->prof;
@@ -718,17 +624,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         {
             const int tid = tid0;
             const auto *ca = as_global(Ap->cond_a), *cb = as_global(Ap->cond_b), *lp = as_global(Ap->lpc);
-            if constexpr (!L2C) {
             for (int i = tid; i < S * RA; i += LPCN_WG_THREADS) {
                 const int s = i / RA, r = i % RA;
                 sm_cond[r * S + s] = ca[((size_t)stream_of(s) * nf + f) * RA + r];
             }
-            }
             if (tid < S * RB) sm_condb[tid] = cb[((size_t)stream_of(tid / RB) * nf + f) * RB + tid % RB];
             if (tid < S * LPCN_LPC_ORDER)
                 sm_lpc[tid] = lp[((size_t)stream_of(tid / LPCN_LPC_ORDER) * nf + f) * LPCN_LPC_ORDER + tid % LPCN_LPC_ORDER];
-            if (LPCN_IS_LEADER || (!TREE2 && tid >= 64 && tid < 64 + S)) {    // predictor lanes; wave 1: threshold lanes
-                const int lstream = stream_of((TREE2 || tid < 64) ? LPCN_LROW : tid - 64);
+            if (tid < 16 * S || (tid >= 64 && tid < 64 + S)) {    // wave 0: predictor lanes; wave 1: threshold lanes
+                const int lstream = stream_of(tid < 64 ? LPCN_LROW : tid - 64);
                 const int fc_ref = Ap->fc_base ? as_global(Ap->fc_base)[lstream] : states[lstream].frame_count;
                 int fc = Ap->fc_advance ? fc_ref + f + 1 : fc_ref;
                 if (fc > 1000) fc = 1000;
@@ -741,21 +645,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         }
         __syncthreads();        // sm_lpc visible to the leaders
         ++seq;
-        if (LPCN_IS_LEADER) {
-            open_sample(live, hist, hist * sm_lpc[LPCN_LROW * LPCN_LPC_ORDER + LPCN_TAP], ((const int *)sm_lead)[LPCN_LROW * 8 + 2], true);   // sm_lpc is [stream][16]
+        if (tid0 < 16 * S) {
+            open_sample(live, hist, hist * sm_lpc[tid0], ((const int *)sm_lead)[LPCN_LROW * 8 + 2], true);   // sm_lpc is [stream][16] = [lane] for wave 0
             publish_indices();
         }
-        if constexpr (TREE2) { if (LPCN_IS_LEADER && LPCN_TAP == 0 && live) draw_thresholds(LPCN_LROW); }
-        else if (tid0 >= 64 && tid0 < 64 + S && live) draw_thresholds(tid0 - 64);
+        if (tid0 >= 64 && tid0 < 64 + S && live) draw_thresholds(tid0 - 64);
         __syncthreads();
-        // TREE2: GRU-A's frame conditioning and the rows' {bias, diag} pairs stay in L2; base pointers of this frame in SGPRs
-        const LPCN_GLOBAL float *cond_f[S] = {}, *abias_g = nullptr, *adiag_g = nullptr;
-        if constexpr (L2C) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) { cond_f[s] = as_global(Ap->cond_a) + ((size_t)stream_of(s) * nf + f) * RA; asm volatile("" : "+s"(cond_f[s])); }
-            abias_g = as_global(Ap->a_bias1); adiag_g = as_global(Ap->a_diag);
-            asm volatile("" : "+s"(abias_g), "+s"(adiag_g));
-        }
         int live_mask = 0;                                   // bit s: stream s produces samples in this frame
 #pragma unroll
         for (int s = 0; s < S; ++s) live_mask |= (sm_idx[S + s] ? 1 : 0) << s;
@@ -938,23 +833,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 LPCN_REMAT_V(r);
                 r = r < 0 ? 0 : r;
                 const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
-                float bias, diag;
-                if constexpr (L2C) { bias = abias_g[r]; diag = adiag_g[r]; } else { bias = sm_abias[2 * r]; diag = sm_abias[2 * r + 1]; }
+                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
                 const bool parked = k == 0 && early_wave;      // slot 0 continues from the partial sums of its early head
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    if constexpr (L2C) pre_c[slot][s] = cond_f[s][r]; else pre_c[slot][s] = sm_cond[r * S + s];
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) pre_b[slot][s] = parked ? sm_pre[r * S + s] : bias + diag * sm_hT[n * S + s];
-            };
-            auto slot0_cond = [&]() {                          // TREE2, run-ahead waves: the frame condition of slot 0's rows, fetched together with their gathered rows
-                if constexpr (L2C) {
-                    int r = row[0];
-                    LPCN_REMAT_V(r);
-                    r = r < 0 ? 0 : r;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) pre_c[0][s] = cond_f[s][r];
+                    pre_b[slot][s] = parked ? sm_pre[r * S + s] : bias + diag * sm_hT[n * S + s];
+                    pre_c[slot][s] = sm_cond[r * S + s];
                 }
             };
             auto row_init = [&](const int k, const int set, const bool to_acc, const bool park = true) {
@@ -1014,8 +898,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     LPCN_REMAT_V(r);
                     r = r < 0 ? 0 : r;
                     const int n = r - 2 * NA;
-                    float bias, diag;
-                    if constexpr (L2C) { bias = abias_g[r]; diag = adiag_g[r]; } else { bias = sm_abias[2 * r]; diag = sm_abias[2 * r + 1]; }
+                    const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
                     for (int s = 0; s < S; ++s) acc[s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
                 }
@@ -1062,8 +945,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 int r = row[0];
                 r = r < 0 ? 0 : r;
                 const int n = r - 2 * NA;
-                float bias, diag;
-                if constexpr (L2C) { bias = abias_g[r]; diag = adiag_g[r]; } else { bias = sm_abias[2 * r]; diag = sm_abias[2 * r + 1]; }
+                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     acc[s] = early_wave ? sm_pre[r * S + s] : acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
@@ -1086,7 +968,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 if ((j == 10 || j == 14 || j == 18) && j >= JSTAR_MIN && j <= JSTAR_MAX && __builtin_expect(j == jstar, 0)) {
                     if (jmode) {
                         row_init(1, 0, false);
-                        if (has2) { row_init(2, 1, false); gather(0, 0); slot0_cond(); }     // (two-slot waves already hold slot 0's rows in set 1)
+                        if (has2) { row_init(2, 1, false); gather(0, 0); }     // (two-slot waves already hold slot 0's rows in set 1)
                         __builtin_amdgcn_s_waitcnt(0xC07F);
                     }
                 }
@@ -1111,7 +993,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 wait_indices();
                 load_indices();
                 gather(1, 0);
-                if (has2) gather(2, 1); else { gather(0, 1); slot0_cond(); }   // a third slot's rows are fetched when set 0 is free again (JSTAR)
+                if (has2) gather(2, 1); else gather(0, 1);   // a third slot's rows are fetched when set 0 is free again (JSTAR)
             }
             // straight-line items JG..NW-1 with ONE exit branch (compile-time recursion instead of an unrolled
             // loop with a break, which the unroller refuses)
@@ -1144,11 +1026,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     if (has2) {
 #pragma unroll
                         for (int s = 0; s < S; ++s)
-                            sm_inh[n * S + s] = (((L2C ? pre_c[0][s] : sm_cond[r * S + s]) + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
+                            sm_inh[n * S + s] = ((sm_cond[r * S + s] + ge[0][0][s]) + ge[0][1][s]) + ge[0][2][s];
                     } else {
 #pragma unroll
                         for (int s = 0; s < S; ++s)
-                            sm_inh[n * S + s] = (((L2C ? pre_c[0][s] : sm_cond[r * S + s]) + ge[1][0][s]) + ge[1][1][s]) + ge[1][2][s];
+                            sm_inh[n * S + s] = ((sm_cond[r * S + s] + ge[1][0][s]) + ge[1][1][s]) + ge[1][2][s];
                     }
                 }
             }
@@ -1167,14 +1049,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // One work item per (neuron, stream): update/reset sigmoids, candidate tanh and the blend
             // (src/nnet.c:441-447).  sm_pre / sm_inh / sm_hT are [row][stream], so item i = n*S + s is
             // simply element i of each gate's third: consecutive lanes touch consecutive words.
-            // gate_items(N, first, stride): items first, first + stride, ... (N of them) of this lane, interleaved
-            auto gate_items = [&](auto nq_c, const int first, const int stride) __attribute__((always_inline)) {
-                constexpr int NQ = decltype(nq_c)::value;
+            {
                 constexpr int NI = NA * S;                                     // items
+                constexpr int NQ = (NI + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
                 float z[NQ], rg[NQ], a[NQ], hold[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int i = first + q * stride;
+                    const int i = tid + q * LPCN_WG_THREADS;
                     const int ic = i < NI ? i : 0;
                     z[q] = sm_pre[ic];
                     rg[q] = sm_pre[NI + ic];
@@ -1185,14 +1066,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 for (int q = 0; q < NQ; ++q) { z[q] = act_sigmoid<FAST>(z[q], sm_tansig); rg[q] = act_sigmoid<FAST>(rg[q], sm_tansig); }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int i = first + q * stride;
+                    const int i = tid + q * LPCN_WG_THREADS;
                     a[q] = a[q] * rg[q] + sm_inh[i < NI ? i : 0];
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) a[q] = act_tanh<FAST>(a[q], sm_tansig);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int i = first + q * stride;
+                    const int i = tid + q * LPCN_WG_THREADS;
                     const int n = i / S, s = i % S;
                     const float hnew = z[q] * hold[q] + (1.f - z[q]) * a[q];      // src/nnet.c:447
                     const float hv = ((live_mask >> s) & 1) ? hnew : hold[q];
@@ -1210,56 +1091,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         }
                     }
                 }
-            };
-            bool p2_streamed = false;                        // (workgroup-uniform)
-            if constexpr (S == 4 && !I8 && !FAST) {
-                if (stream_gates) {
-                    // item i = n*4 + s belongs to state block i / 16, i.e. to range i / 256: waves 0..3 (the GRU-B waves) take range 0,
-                    // waves 4..7 ranges 1..5 in order, two at a time (the pair's latencies overlap), and announce each
-                    p2_streamed = true;
-                    ++gbseq;
-#ifndef LPCN_SG_MODE
-#define LPCN_SG_MODE 2
-#endif
-                    if (tid < 256) {
-                        if constexpr (LPCN_SG_MODE < 2) {
-                            gate_items(std::integral_constant<int, 1>{}, tid, 0);
-                            range_arrive(0);
-                        } else {
-                            gate_items(std::integral_constant<int, 2>{}, tid, 256);
-                            range_arrive(0); range_arrive(1);
-                        }
-                    } else {
-                        if constexpr (LPCN_SG_MODE == 0) {
-                            gate_items(std::integral_constant<int, 2>{}, tid, 256);
-                            range_arrive(1); range_arrive(2);
-                            gate_items(std::integral_constant<int, 2>{}, tid + 512, 256);
-                            range_arrive(3); range_arrive(4);
-                            gate_items(std::integral_constant<int, 1>{}, tid + 1024, 0);
-                            range_arrive(5);
-                        } else if constexpr (LPCN_SG_MODE == 1) {
-                            gate_items(std::integral_constant<int, 3>{}, tid, 256);
-                            range_arrive(1); range_arrive(2); range_arrive(3);
-                            gate_items(std::integral_constant<int, 2>{}, tid + 768, 256);
-                            range_arrive(4); range_arrive(5);
-                        } else if constexpr (LPCN_SG_MODE == 2) {
-                            gate_items(std::integral_constant<int, 2>{}, tid + 256, 256);
-                            range_arrive(2); range_arrive(3);
-                            gate_items(std::integral_constant<int, 2>{}, tid + 768, 256);
-                            range_arrive(4); range_arrive(5);
-                        } else {
-                            gate_items(std::integral_constant<int, 4>{}, tid + 256, 256);
-                            range_arrive(2); range_arrive(3); range_arrive(4); range_arrive(5);
-                        }
-                        ranges_wait(6);                      // the early candidate heads read all of the new state (and re-use sm_pre)
-                    }
-                }
             }
-            if (!p2_streamed) {
-                constexpr int NQ = (NA * S + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
-                gate_items(std::integral_constant<int, NQ>{}, tid, LPCN_WG_THREADS);
-                __syncthreads();                                               // B2
-            }
+            __syncthreads();                                                   // B2
             LPCN_PROF(1);
 
             LPCN_REMAT_V(tid);
@@ -1290,7 +1123,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 fcb = fc_b_g[chan * 256 + node]; fcf = fc_f_g[chan * 256 + node];
             };
             // (tried on the 128-VGPR FAST kernels: fetching the row only when the tree needs it -- 160 vs 168 M samples/s on int8)
-            if constexpr (!TREE2) load_fc();
+            load_fc();
             LPCN_PROF(7);      // dual-FC prefetch issue
             // ----------------------------------------------------- P3: GRU-B (wave = stream)
             // FAST, int8 blobs, dense input matrix: integer block sums are exact in any order, so the 96 input blocks of a
@@ -1426,8 +1259,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if constexpr (!I8 && !FAST) {
                 if (gb_scalar) { ++gbseq; if (!gate_wave) mirror_arrive(); }
             }
-            // (L2C) the next sample's row constants: the GRU-B waves fetch them behind their mat-vec -- in front of it the loads would
-            // land in registers the assembly block owns, and the copies out of those wait for L2
             float zrh = 0.f, rec = 0.f;
             const int s = gb_split ? wave / GB_W : wave;     // (stream of a gate wave)
             const int r = lane < RB ? lane : RB - 1;
@@ -1579,18 +1410,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::bw + (sm_bstart[g] * 8 + ri) * 16 + ((0x321100 >> (4 * g)) & 15) * 128);
                     uint32_t hp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::hA + s * 16);
                     if constexpr (S == 4) {
-                        if (p2_streamed) {
-                            ranges_wait(2);                  // the loop's first trip reads into range 1; it checks the later ranges itself
-                            uint32_t cp32 = gcnt_addr + 4u;
-                            const int want = gbseq * (LPCN_WAVES / 2);
-                            asm volatile(
-#include "grub_lds_poll_loop_s4.inc"
-                                : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32), [cp] "+v"(cp32) : [want] "s"(want) : LPCN_GRUB_LDSP_CLOBBERS);
-                        } else {
                         asm volatile(
 #include "grub_lds_loop_s4.inc"
                             : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
-                        }
                     } else if constexpr (S == 2) {
                         asm volatile(
 #include "grub_lds_loop_s2.inc"
@@ -1667,7 +1489,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #undef LPCN_SB
                 }
                 LPCN_PROF(8);      // GRU-B input mat-vec
-                if constexpr (!TREE2) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
             } else if (early_wave) {
                 // ---- the head of the next sample's candidate chains (runs in the shadow of GRU-B)
                 run_head();
@@ -1696,99 +1518,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                 }
             }
-            if constexpr (TREE2) {
-                // ---- from here to the published indices stream s is the business of wave s alone
-                const bool more = smp + 1 < frame_len;
-                if (more) ++seq;
-                if (gate_wave) {
-                    const int k = (lane >> 1) & 15, tchan = lane & 1;        // tree slot (heap index within a round: 1..15) and channel
-                    const int kk = k ? k : 1;
-                    const int dlev = 31 - __clz(kk), rpath = kk - (1 << dlev);
-                    const float *const sm_fcb = (const float *)(smem + L::fcb(Ap->nb_b, I8));
-                    const float *const sm_fcf = (const float *)(smem + L::fcf(Ap->nb_b, I8));
-                    float hb[NB];
-                    {
-                        const float4 *hp = (const float4 *)(sm_hB + s * NB);  // (this wave's own LDS writes: in order)
-#pragma unroll
-                        for (int q = 0; q < NB / 4; ++q) { const float4 t = hp[q]; hb[4 * q] = t.x; hb[4 * q + 1] = t.y; hb[4 * q + 2] = t.z; hb[4 * q + 3] = t.w; }
-                    }
-                    // one round: this lane's (node, channel) logit part, partner channel from the neighbouring lane, decision bits of the 15 nodes
-                    auto tree_round = [&](const int node, const int level) -> unsigned long long {
-                        const float4 *wp = (const float4 *)(smem + L::fcw(Ap->nb_b, I8)) + (node * 2 + tchan) * (NB / 4);
-                        float tw[NB];
-#pragma unroll
-                        for (int q = 0; q < NB / 4; ++q) { const float4 t = wp[q]; tw[4 * q] = t.x; tw[4 * q + 1] = t.y; tw[4 * q + 2] = t.z; tw[4 * q + 3] = t.w; }
-                        float sum = sm_fcb[tchan * 256 + node];
-                        const float fac = sm_fcf[tchan * 256 + node], thr = sm_thr[s * 8 + level];
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) sum = sum + tw[j] * hb[j];                               // src/nnet.c:194-199
-                        const float v = fac * lpcn_tanh(sum, sm_tansig);
-                        const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-                        const float logit = v + vo;                                 // sum1 += sum2
-                        return __ballot((thr < logit) && tchan == 0 && k > 0 && lane < 32);
-                    };
-                    auto walk4 = [](const unsigned long long m) {                   // (wave-uniform: scalar code)
-                        int val = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) { const int node = (1 << b) | val; val = (val << 1) | (int)((m >> (2 * node)) & 1ull); }
-                        return val;
-                    };
-                    unsigned long long t_b4 = 0;
-                    if (tracing_any) t_b4 = __builtin_amdgcn_s_memtime();
-                    const int v4 = __builtin_amdgcn_readfirstlane(walk4(tree_round(kk, dlev)));                       // levels 0..3
-                    const int tree_val = (v4 << 4) | __builtin_amdgcn_readfirstlane(walk4(tree_round(((16 + v4) << dlev) | rpath, 4 + dlev)));   // levels 4..7
-                    // ---- leader: lanes 0..15 hold the stream's LPC history (lane = tap)
-                    if (lane < 16) {
-                        const int lrow = s, tap = lane;
-                        const float lpc_tap = sm_lpc[lrow * LPCN_LPC_ORDER + tap];
-                        const float prod_old = row_shr1(hist, 0.f) * lpc_tap;
-                        float pcm = 0.f, deemph = 0.f;
-                        int exc = 0;
-                        if (live) {
-                            const float pred = sm_lead[lrow * 8 + 0];
-                            deemph = sm_lead[lrow * 8 + 1];
-                            exc = tree_val;
-                            if (smp < preload) {                                        // src/lpcnet.c:256-258
-                                const float x = (float)sm_pcm[lrow * LPCN_FRAME_SIZE + smp];
-                                exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
-                                pcm = x - 0.85f * deemph;
-                            } else {
-                                pcm = pred + sm_ulaw[exc];                              // src/lpcnet.c:260
-                            }
-                        }
-                        {                                            // history shifts by one, the new sample enters at tap 0 (src/lpcnet.c:262-263)
-                            const float shifted = row_shr1(hist, pcm);
-                            hist = live ? shifted : hist;
-                        }
-                        if (tap == 0 && live) ((int *)sm_lead)[lrow * 8 + 2] = exc;
-                        if (tracing_lane0(live)) {
-                            LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
-                            d[1] = (float)(sm_idx[0] & 0xFF); d[2] = (float)((sm_idx[0] >> 8) & 0xFF);
-                        }
-                        // the next sample's indices first: the other waves are waiting for them
-                        if (more) { open_sample(live, pcm, tap == 0 ? pcm * lpc_tap : prod_old, exc, false); publish_indices(); }
-                        if (tracing_lane0(live))
-                            as_global_rw(Ap->dbg)[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 405] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_b4);
-                        if (tap == 0) {
-                            if (live) {
-                                if (tracing_lane0(true)) {
-                                    LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 400;
-                                    d[0] = (float)exc; d[3] = pcm + 0.85f * deemph; d[4] = pcm - sm_ulaw[exc];
-                                    d[6] = (float)tree_val;
-                                }
-                                pcm = pcm + 0.85f * deemph;
-                                sm_lead[lrow * 8 + 1] = pcm;                            // de-emphasis memory
-                                if (smp >= preload) sm_pcm[lrow * LPCN_FRAME_SIZE + smp] = (short)lpcn_round_pcm(pcm);
-                            } else {
-                                sm_pcm[lrow * LPCN_FRAME_SIZE + smp] = 0;
-                            }
-                            if (more && live) draw_thresholds(lrow);
-                        }
-                    }
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                if (tracing_any) __syncthreads();              // tests: the trace below wants every wave's state of this sample (workgroup-uniform condition)
-            }
             if constexpr (I8) {
                 // (int8 blobs: waves 2 and 3 carry candidate heads too -- at S <= 2 they run no GRU-B -- and FAST splits GRU-B over
                 // all waves with gate waves 0, GB_W, 2 GB_W, ...: a wave can be both a gate wave and an early wave; it computes its
@@ -1796,7 +1525,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 if (gate_wave && early_wave) run_head();
             }
             LPCN_PROF(11);     // GRU-B gates (gate waves) / early GRU-A slot (the others)
-            if constexpr (!TREE2) {
             __syncthreads();                                                   // B3
             LPCN_PROF(2);
 
@@ -1805,44 +1533,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 const int node_level = node > 0 ? 31 - __clz(node) : 0;
                 // (tried: the S x 16 GRU-B state values through one LDS read per lane + v_readlane into SGPR operands instead of
                 // S x 4 broadcast ds_read_b128 per wave: P4 2.2 k -> 2.8 k clk, the 64 v_readlane cost more than the reads)
-#ifndef LPCN_TREE_MFMA
-#define LPCN_TREE_MFMA 0        // PARITY, S = 4: the tree's 16-term sums with the matrix pipe as exact multiplier + packed adds (like the GRU-A items)
-#endif
-                float sum4[4] = {fcb, fcb, fcb, fcb};
-                if constexpr (!FAST && S == 4 && LPCN_TREE_MFMA) {
-                    // lane k of a quad supplies stream k's GRU-B state, every lane its own row's weight: register k of the result is
-                    // this row's product with stream k, bit for bit v_mul_f32's (C = -0.0); sums in the reference's order j = 0..15
-                    typedef float f4 __attribute__((ext_vector_type(4)));
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    f4 nz = {-0.f, -0.f, -0.f, -0.f};
-                    asm volatile("" : "+v"(nz));
-                    float hk[NB];
-                    {
-                        const float4 *hp = (const float4 *)(sm_hB + (lane & 3) * NB);
-#pragma unroll
-                        for (int q = 0; q < NB / 4; ++q) { const float4 t = hp[q]; hk[4 * q] = t.x; hk[4 * q + 1] = t.y; hk[4 * q + 2] = t.z; hk[4 * q + 3] = t.w; }
-                    }
-                    f2 s01 = {fcb, fcb}, s23 = {fcb, fcb};
-#pragma unroll
-                    for (int j0 = 0; j0 < NB; j0 += 4) {
-                        f4 pv[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) pv[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(hk[j0 + c], fcw[j0 + c], nz, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            s01 = s01 + __builtin_shufflevector(pv[c], pv[c], 0, 1);
-                            s23 = s23 + __builtin_shufflevector(pv[c], pv[c], 2, 3);
-                        }
-                    }
-                    sum4[0] = s01[0]; sum4[1] = s01[1]; sum4[2] = s23[0]; sum4[3] = s23[1];
-                }
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     float sum = fcb;
-                    if constexpr (!FAST && S == 4 && LPCN_TREE_MFMA) {
-                        sum = sum4[s];
-                    } else
                     if constexpr (FAST) {
                         if (fc_f16) {
                             // fp16 dual FC (FAST sub-option): weights and GRU-B state as halves, fp32 accumulation, two MACs per
@@ -1967,7 +1660,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
             }
             if (more && tid >= 64 && tid < 64 + S && live) draw_thresholds(tid - 64);
-            }   // !TREE2
             if (tracing) {
                 LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE;
                 if (tid < NA) d[tid] = sm_hT[tid * S];
@@ -2009,7 +1701,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         }
         for (int i = tid; i < S * NB; i += LPCN_WG_THREADS)
             if (i / NB < n_valid) states[s0 + i / NB].gru_b[i % NB] = sm_hB[i];
-        if (LPCN_IS_LEADER && LPCN_LROW < n_valid) states[s0 + LPCN_LROW].last_sig[LPCN_TAP] = hist;
+        if (tid < 16 * S && LPCN_LROW < n_valid) states[s0 + LPCN_LROW].last_sig[LPCN_TAP] = hist;
         if (tid < n_valid) {
             auto *st = &states[s0 + tid];
             const int *li = (const int *)sm_lead + tid * 8;
