@@ -91,14 +91,18 @@ static int cmp_group_desc(const void *a, const void *b)
  * smallest step estimate wins:  T(wave) = max(gather lands, candidate tail done) + update/reset items x clk per item
  * (constants from the in-kernel phase clocks, profiles/r03_phase_clocks.txt). */
 typedef struct { int items[LPCN_WAVES], nsl[LPCN_WAVES], nzr[LPCN_WAVES], cand[LPCN_WAVES], zr_items[LPCN_WAVES]; } deal_state;
-static int g_deal_eh = 20;
-static int g_deal_fast = 0;             /* packing the FAST arithmetic's own image (lpcn_model_pack_fast) */
-static int g_deal_hw = LPCN_WAVES / 2;  /* first wave that may carry a candidate head (float: 4 = the waves that never run GRU-B; int8: see pack_gru_a) */
+/* Parameters of one dealing, local to the pack_gru_a() call that fills them (model loads may run concurrently). */
+typedef struct {
+    int eh;                     /* head length of the early candidate items */
+    int hw;                     /* first wave that may carry a candidate head (float: 4 = the waves that never run GRU-B; int8: see pack_gru_a) */
+    int tg, t0a, t0b, ci, cu;   /* deal_wave_cost */
+    int tl;                     /* wave 0 leads the streams: its own part of GRU-A starts this much later */
+} deal_params;
 
-static int deal_head(int w, int cand)
+static int deal_head(const deal_params *dp, int w, int cand)
 {
-    if (w < g_deal_hw || cand <= 0) return 0;
-    const int eh = g_deal_eh < LPCN_EARLY_MAX ? g_deal_eh : LPCN_EARLY_MAX;
+    if (w < dp->hw || cand <= 0) return 0;
+    const int eh = dp->eh < LPCN_EARLY_MAX ? dp->eh : LPCN_EARLY_MAX;
     return cand < eh ? cand : eh;
 }
 
@@ -107,23 +111,22 @@ static int deal_head(int w, int cand)
  *    been folded into the start values: TG;
  *  - a candidate tail of at least 10 items (the kernel's run-ahead mode) starts at T0 and keeps the wave busy at CI clk per
  *    item (both waves of a SIMD running items) -- a shorter tail waits for the gather like everything else. */
-static int g_deal_tg = 5000, g_deal_t0a = 1600, g_deal_t0b = 900, g_deal_ci = 395, g_deal_cu = 320;
-static long deal_wave_cost(const deal_state *d, int w)
+static long deal_wave_cost(const deal_params *dp, const deal_state *d, int w)
 {
-    const int tail = d->cand[w] - deal_head(w, d->cand[w]);           /* candidate items left for the sample step itself */
-    const long after_gather = g_deal_tg + (long)g_deal_cu * d->zr_items[w];
+    const int tail = d->cand[w] - deal_head(dp, w, d->cand[w]);       /* candidate items left for the sample step itself */
+    const long after_gather = dp->tg + (w == 0 ? dp->tl : 0) + (long)dp->cu * d->zr_items[w];
     long t;
     if (tail >= 10) {
-        t = (w < g_deal_hw ? g_deal_t0a : g_deal_t0b) + (long)g_deal_ci * (tail + d->zr_items[w]);
+        t = (w < dp->hw ? dp->t0a : dp->t0b) + (w == 0 ? dp->tl : 0) + (long)dp->ci * (tail + d->zr_items[w]);
         if (t < after_gather) t = after_gather;
     } else {
-        t = after_gather + (long)g_deal_cu * tail;
+        t = after_gather + (long)dp->cu * tail;
     }
     return t + 100L * d->nsl[w];
 }
 
 /* slot_max[0..nc) candidate slots, [nc..ns) update/reset slots (both descending); returns 0 and wave_of[] or -1 */
-static int deal_v2(const int *slot_max, int nc, int ns, int cap, int *wave_of)
+static int deal_v2(const deal_params *dp, const int *slot_max, int nc, int ns, int cap, int *wave_of)
 {
     int perm[8], used[LPCN_WAVES] = {0}, best_wave[32];
     long best_max = -1, best_sum = 0;
@@ -150,7 +153,7 @@ static int deal_v2(const int *slot_max, int nc, int ns, int cap, int *wave_of)
                     if (d.nsl[w] >= maxsl || d.items[w] + slot_max[z] > cap) continue;
                     deal_state t = d;
                     t.items[w] += slot_max[z]; t.nsl[w]++; t.nzr[w]++; t.zr_items[w] += slot_max[z];
-                    const long c = deal_wave_cost(&t, w);
+                    const long c = deal_wave_cost(dp, &t, w);
                     if (pick < 0 || c < pick_cost) { pick = w; pick_cost = c; }
                 }
                 if (pick < 0) { ok = 0; break; }
@@ -159,7 +162,7 @@ static int deal_v2(const int *slot_max, int nc, int ns, int cap, int *wave_of)
             }
             if (ok) {
                 long mx = 0, sum = 0;
-                for (int w = 0; w < LPCN_WAVES; w++) { const long c = deal_wave_cost(&d, w); if (c > mx) mx = c; sum += c; }
+                for (int w = 0; w < LPCN_WAVES; w++) { const long c = deal_wave_cost(dp, &d, w); if (c > mx) mx = c; sum += c; }
                 if (best_max < 0 || mx < best_max || (mx == best_max && sum < best_sum)) {
                     best_max = mx; best_sum = sum;
                     memcpy(best_wave, trial, sizeof(int) * (size_t)ns);
@@ -193,8 +196,9 @@ static int deal_v2(const int *slot_max, int nc, int ns, int cap, int *wave_of)
  *     have (nearly) equal trip counts;
  *  2. longest-processing-time assignment of slots to waves (<= 3 slots per wave);
  *  3. per lane and item: the 4 weights of (row, block) and the block's input index. */
-static int pack_gru_a(lpcn_model_host *m)
+static int pack_gru_a(lpcn_model_host *m, int for_fast)
 {
+    deal_params dpv, *const dp = &dpv;
     enum { NG = LPCN_ROWS_A / 8, NSLOT = NG / 8 };
     row_group g[NG];
     const int *idx = m->a_idx;
@@ -207,24 +211,26 @@ static int pack_gru_a(lpcn_model_host *m)
     const int deal2 = !m->is_int8 || !(old_i8 && old_i8[0] == '1');      /* split candidate chains (see deal_wave_cost) */
     {
         const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (float default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
-        g_deal_eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : LPCN_DEAL_EH_F32);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
+        dp->eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : LPCN_DEAL_EH_F32);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
         {   /* int8 blobs run two streams per workgroup (two workgroups per CU): waves 2 and 3 run no GRU-B there either, and wave 3
              * takes a head too (at four streams per workgroup it runs it behind GRU-B's gate stage: 141.7 -> 132 M with both,
              * but the auto-tune does not pick S = 4 for int8 batches of this size) */
             const char *hw = getenv("LPCN_DEAL_HW");
-            g_deal_hw = (hw && *hw) ? atoi(hw) : (m->is_int8 ? LPCN_DEAL_HW_I8 : LPCN_WAVES / 2);
-            if (g_deal_hw < 2) g_deal_hw = 2;
-            if (g_deal_hw > LPCN_WAVES / 2) g_deal_hw = LPCN_WAVES / 2;
+            dp->hw = (hw && *hw) ? atoi(hw) : (m->is_int8 ? LPCN_DEAL_HW_I8 : LPCN_WAVES / 2);
+            if (dp->hw < 2) dp->hw = 2;
+            if (dp->hw > LPCN_WAVES / 2) dp->hw = LPCN_WAVES / 2;
+            if (!m->is_int8) dp->hw = LPCN_WAVES / 2;     /* float kernels re-run a head only on waves that never run GRU-B (a gate wave's parked sums would go stale) */
         }
-        if (g_deal_fast) {                                /* FAST int8 (GRU-B split over all waves: no shadow to hide a head in): 0 / 6 / 14 -> 184 / 163 / 167 M */
+        if (for_fast) {                                /* FAST int8 (GRU-B split over all waves: no shadow to hide a head in): 0 / 6 / 14 -> 184 / 163 / 167 M */
             const char *ehf = getenv("LPCN_DEAL_EH_FAST");
-            g_deal_eh = (ehf && *ehf) ? atoi(ehf) : LPCN_DEAL_EH_FAST_I8;
+            dp->eh = (ehf && *ehf) ? atoi(ehf) : LPCN_DEAL_EH_FAST_I8;
         }
-        if (g_deal_eh < 0) g_deal_eh = 0;
-        if (m->is_int8) { g_deal_tg = 4200; g_deal_t0a = 1600; g_deal_t0b = 900; g_deal_ci = 250; g_deal_cu = 220; }
-        else            { g_deal_tg = 5000; g_deal_t0a = 1600; g_deal_t0b = 900; g_deal_ci = 395; g_deal_cu = 320; }
-        const char *cm = getenv("LPCN_DEAL_COST");        /* tools: "TG,T0a,T0b,CI,CU" of deal_wave_cost */
-        if (cm && *cm) sscanf(cm, "%d,%d,%d,%d,%d", &g_deal_tg, &g_deal_t0a, &g_deal_t0b, &g_deal_ci, &g_deal_cu);
+        if (dp->eh < 0) dp->eh = 0;
+        if (m->is_int8) { dp->tg = 4200; dp->t0a = 1600; dp->t0b = 900; dp->ci = 250; dp->cu = 220; }
+        else            { dp->tg = 5000; dp->t0a = 1600; dp->t0b = 900; dp->ci = 395; dp->cu = 320; }
+        dp->tl = 0;
+        const char *cm = getenv("LPCN_DEAL_COST");        /* tools: "TG,T0a,T0b,CI,CU[,TL]" of deal_wave_cost */
+        if (cm && *cm) sscanf(cm, "%d,%d,%d,%d,%d,%d", &dp->tg, &dp->t0a, &dp->t0b, &dp->ci, &dp->cu, &dp->tl);
     }
     if (deal2) {                                    /* candidate groups first (6 slots), then update/reset groups (12 slots) */
         row_group c[NG], z[NG];
@@ -309,11 +315,11 @@ static int pack_gru_a(lpcn_model_host *m)
         int done = 0;
         for (const int *c = caps; *c && !done; c++) {
             if (slot_max[0] > *c) continue;
-            if (deal_v2(slot_max, nc, NSLOT, *c, w2) == 0) done = 1;
+            if (deal_v2(dp, slot_max, nc, NSLOT, *c, w2) == 0) done = 1;
         }
         if (done) {
             /* the lightest GRU-B wave leads the streams (wave 0), the next draws the thresholds (wave 1) */
-            const int nh = g_deal_hw;                 /* (waves without a head: interchangeable) */
+            const int nh = dp->tl ? 0 : dp->hw;        /* (waves without a head: interchangeable -- unless the cost model told wave 0 apart) */
             int load4[LPCN_WAVES / 2] = {0}, ord[LPCN_WAVES / 2], newid[LPCN_WAVES];
             for (int sl = 0; sl < NSLOT; sl++) if (w2[sl] < nh) load4[w2[sl]] += slot_max[sl];
             for (int i = 0; i < nh; i++) ord[i] = i;
@@ -351,7 +357,7 @@ static int pack_gru_a(lpcn_model_host *m)
         int k = 0;
         if (hslot >= 0) slot_at[w][k++] = hslot;
         for (int i = 0; i < n; i++) if (list[i] != hslot) slot_at[w][k++] = list[i];
-        m->pk_a_head[w] = (hslot >= 0) ? deal_head(w, slot_max[hslot]) : 0;
+        m->pk_a_head[w] = (hslot >= 0) ? deal_head(dp, w, slot_max[hslot]) : 0;
     }
     for (int w = 0; w < LPCN_WAVES; w++) {
         int cur = 0;
@@ -498,7 +504,7 @@ int lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len)
     if (!(m->b_w = (const float *)blob_need(rec, n, "gru_b_weights", q * 32 * (size_t)m->nb_b))) return -1;
     if (!(m->b_rec = (const float *)blob_need(rec, n, "gru_b_recurrent_weights", q * LPCN_ROWS_B * LPCN_N_B))) return -1;
 
-    if (pack_gru_a(m) || pack_gru_b(m)) { lpcn_model_release(m); return -1; }
+    if (pack_gru_a(m, 0) || pack_gru_b(m)) { lpcn_model_release(m); return -1; }
     return 0;
 }
 
@@ -513,9 +519,7 @@ int lpcn_model_pack_fast(const lpcn_model_host *m, lpcn_model_host *f)
     f->pk_a_w = NULL; f->pk_a_wq = NULL; f->pk_a_blk = NULL; f->pk_a_row = NULL;
     f->pk_b_w = NULL; f->pk_b_wq = NULL; f->pk_b_start = NULL; f->pk_b_blk = NULL;
     for (int i = 0; i < 3; i++) f->pk_emb[i] = NULL;
-    g_deal_fast = 1;
-    const int rc = pack_gru_a(f);
-    g_deal_fast = 0;
+    const int rc = pack_gru_a(f, 1);
     if (rc) { lpcn_model_release(f); return -1; }
     return 0;
 }
@@ -624,7 +628,7 @@ int lpcn_model_selftest(const lpcn_model_host *m)
                 seen[row] = 1;
                 if (m->pk_a_allh[wv][k] && row < 2 * LPCN_N_A) { rc = 3; goto done; }
                 const int head = k == 0 ? m->pk_a_head[wv] : 0;       /* slot 0's early items sit end-aligned */
-                if ((wv < 2 && m->pk_a_head[wv]) || head < 0 || head > LPCN_EARLY_MAX || m->pk_a_bound[wv][LPCN_MAX_SLOTS] + m->pk_a_head[wv] > m->nw) { rc = 7; goto done; }
+                if ((wv < LPCN_WAVES / 2 && m->pk_a_head[wv]) || head < 0 || head > LPCN_EARLY_MAX || m->pk_a_bound[wv][LPCN_MAX_SLOTS] + m->pk_a_head[wv] > m->nw) { rc = 7; goto done; }
                 for (int jj = j0 - head; jj < j1; jj++) {
                     const int j = jj < j0 ? m->nw + (jj - j0) : jj;
                     size_t item = ((size_t)wv * m->nw + j) * 64 + lane;

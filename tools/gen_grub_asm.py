@@ -28,7 +28,7 @@ OFF, OFFC, CNT, DUMMY = 68, 69, 70, 71
 import sys
 PHASE = int(sys.argv[sys.argv.index("--phase") + 1]) if "--phase" in sys.argv else 0
 MASK48 = "--mask48" in sys.argv
-POLL = "--poll" in sys.argv
+RING = int(sys.argv[sys.argv.index("--ring") + 1]) if "--ring" in sys.argv else 4
 
 
 def pk_mul(dst, sreg, vreg):
@@ -123,11 +123,16 @@ def main_lds(S):
     Layout of the state: [block][stream][4] floats, 16 B pad every 4 blocks (Lds<S>::ha_off)."""
     stride = 16 * S
     ha_off = lambda p: p * stride + (p >> 2) * 16
-    WR = [224, 228, 232, 236]      # weight ring (float4 per block)
-    HR = [240, 244, 248, 252]      # state ring
-    PS = [216, 220]                # product sets
+    R = RING                       # ring slots = blocks in flight + 1
+    base = 256 - 8 - 8 * R
+    PS = [base, base + 4]          # product sets
+    WR = [base + 8 + 4 * i for i in range(R)]              # weight ring (float4 per block)
+    HR = [base + 8 + 4 * R + 4 * i for i in range(R)]      # state ring
     CNT = 70
-    BPT = 16                       # blocks per trip
+    BPT = 16 if 96 % R else (R * (16 // R) if 96 % (R * (16 // R)) == 0 else 12)     # blocks per trip: a multiple of the ring size that divides 96
+    if BPT % R: BPT = {4: 16, 5: 15, 6: 12, 3: 12, 8: 16}.get(R, 16)
+    assert 96 % BPT == 0 or R == 5
+    LA = R - 1
     lines = []
     rdw = lambda slot, blk: f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}"
     rdh = lambda slot, blk: f"ds_read_b128 v[{HR[slot]}:{HR[slot] + 3}], %[hp] offset:{ha_off(blk)}"
@@ -136,28 +141,17 @@ def main_lds(S):
     lines += [f"s_mov_b32 s{CNT}, {96 // BPT}"]
     if MASK48:          # only the 48 row lanes take part: a quarter less LDS return traffic per read
         lines += ["s_mov_b64 s[72:73], exec", "s_bfm_b64 exec, 48, 0"]
-    for b in range(3):
-        lines += [rdw(b, b), rdh(b, b)]
-    lines += ["s_waitcnt lgkmcnt(4)"] + prod(0, 0)
+    for b in range(LA):
+        lines += [rdw(b % R, b), rdh(b % R, b)]
+    lines += [f"s_waitcnt lgkmcnt({2 * (LA - 1)})"] + prod(0, 0)
     lines += [".p2align 4"] + ["s_nop 0"] * PHASE
     lines += ["1:"]
     for k in range(BPT):
-        pr = prod((k + 1) & 1, (k + 1) & 3)
+        pr = prod((k + 1) & 1, (k + 1) % R)
         a = [f"v_add_f32 %[z], %[z], v{PS[k & 1] + j}" for j in range(4)]
-        if POLL and k == 13:
-            # the reads from here on reach into the NEXT range of 16 blocks: its ready counter (sampled at block 5 of this trip, long
-            # returned: LDS completes in order) must have reached `want`; otherwise spin on it (rare: the gate stage produces a range
-            # faster than this loop consumes one)
-            lines += ["v_readfirstlane_b32 s74, v215", "s_cmp_ge_i32 s74, %[want]", "s_cbranch_scc1 3f",
-                      "2:", "s_sleep 1", "ds_read_b32 v215, %[cp]", "s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 s74, v215",
-                      "s_cmp_ge_i32 s74, %[want]", "s_cbranch_scc0 2b", "3:"]
-        lines += [rdw((k + 3) & 3, k + 3), rdh((k + 3) & 3, k + 3)]
-        if POLL and k == 5:
-            lines += ["ds_read_b32 v215, %[cp]"]
-        # (one more LDS operation in flight behind block 5's reads until it has returned: the counts stay upper bounds of what must be done)
-        lines += ["s_waitcnt lgkmcnt(%d)" % (5 if POLL and k == 5 else 4), a[0], pr[0], a[1], pr[1], a[2], a[3]]
-    if POLL:
-        lines += ["v_add_u32 %[cp], 4, %[cp]"]
+        lines += [rdw((k + LA) % R, k + LA), rdh((k + LA) % R, k + LA), f"s_waitcnt lgkmcnt({2 * (LA - 1)})",
+                  a[0], pr[0], a[1], pr[1], a[2], a[3]]
+    assert BPT % 2 == 0 and BPT % R == 0
     lines += [f"v_add_u32 %[wp], {BPT * 128}, %[wp]",
               f"v_add_u32 %[hp], {ha_off(BPT)}, %[hp]",
               f"s_sub_u32 s{CNT}, s{CNT}, 1",
@@ -168,10 +162,8 @@ def main_lds(S):
         lines += ["s_mov_b64 exec, s[72:73]"]
     print("// generated by tools/gen_grub_asm.py --lds %d -- do not edit" % S)
     print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of the stream's state, block 0 (in/out VGPR)")
-    clob = [f"s{CNT}"] + (["s72", "s73"] if MASK48 else []) + (["s74", "v215"] if POLL else []) + [f"v{i}" for i in range(216, 256)]
-    name = "LPCN_GRUB_LDSP_CLOBBERS" if POLL else "LPCN_GRUB_LDS_CLOBBERS"
-    if POLL:
-        print("// + %[cp] LDS byte address of the ready counter of block range 1 (in/out VGPR; one i32 per range of 16 blocks, two always-ready words behind the last), %[want] value a ready counter has reached (SGPR)")
+    clob = [f"s{CNT}"] + (["s72", "s73"] if MASK48 else []) + [f"v{i}" for i in range(base, 256)]
+    name = "LPCN_GRUB_LDS_CLOBBERS"
     print("#undef " + name)
     print("#define " + name + " " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
     for ln in lines:
