@@ -157,7 +157,7 @@ template <int S> struct Lds {
     static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
     static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
-    static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 16 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
+    static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 28 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
     static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }                          // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
     static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         }
         const auto *bw = as_global(Ap->b_w);
         constexpr int BW_DW = I8 ? 8 : 32;                  // dwords per GRU-B block
-        for (int i = tid; i < (nb_b + (I8 ? 16 : 8)) * BW_DW; i += LPCN_WG_THREADS) {
+        for (int i = tid; i < (nb_b + (I8 ? 28 : 8)) * BW_DW; i += LPCN_WG_THREADS) {
             int di = i;
             if constexpr (FAST && !I8 && S >= 2) {
                 // the matrix-pipe GRU-B (dense input matrix) reads 4 rows x 16 consecutive blocks per instruction: [row quad][block][row][4]
@@ -456,6 +456,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 if (b_dense && i < nb_b * BW_DW) {
                     const int blk_abs = i >> 5, ri = (i >> 2) & 7, c = i & 3;
                     di = ((((blk_abs / 96) * 2 + (ri >> 2)) * 96 + blk_abs % 96) * 4 + (ri & 3)) * 4 + c;
+                }
+            }
+            if constexpr (I8) {
+                // (int8 blobs, dense matrix: a row group is 24 quads of 4 blocks = 3 072 B -- the same bank phase for all six; same cure)
+                if (b_dense) {
+                    if (i < nb_b * BW_DW) di = i + ((0x321100 >> (4 * ((i >> 5) / 24))) & 15) * 32;
+                    else if (i < (nb_b + 4) * BW_DW) di = i + 3 * 32;
+                    else continue;
                 }
             }
             if constexpr (!FAST && !I8) {
@@ -1138,7 +1146,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     constexpr int QP = 24 / GB_W;            // quads of 4 blocks per wave: 3, 6 or 12
                     const int s2 = wave / GB_W, part = wave - s2 * GB_W;
                     const int r = lane < RB ? lane : RB - 1;
-                    const i4 *wq = (const i4 *)(smem + L::bw) + (sm_bstart[r >> 3] >> 2) * 8 + (r & 7) + part * QP * 8;
+                    const i4 *wq = (const i4 *)(smem + L::bw) + (sm_bstart[r >> 3] >> 2) * 8 + (r & 7) + part * QP * 8 + ((0x321100 >> (4 * (r >> 3))) & 15) * 8;
                     const i4 *xq4 = (const i4 *)(smem + L::xqT + s2 * 384) + part * QP;
                     int z0 = 0, z1 = 0, z2 = 0, z3 = 0;
 #pragma unroll
@@ -1295,7 +1303,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     rec = (float)rsum * QS1;
                     const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
                     const int nq = (bend - bbeg) >> 2;
-                    const i4 *wq = (const i4 *)(smem + L::bw) + (bbeg >> 2) * 8 + ri;
+                    const i4 *wq = (const i4 *)(smem + L::bw) + (bbeg >> 2) * 8 + ri + (b_dense ? ((0x321100 >> (4 * g)) & 15) * 8 : 0);
                     const unsigned char *xb = smem + L::xqT + s * 384;
                     if (b_dense) {
                         const i4 *xq4 = (const i4 *)xb;      // all 96 input blocks in order: 24 quads, 8 quads of reads in flight
@@ -1337,7 +1345,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     // input part: four blocks of this lane's row per 16-byte read; groups are padded to x4
                     const int bbeg = sm_bstart[g], bend = sm_bstart[g + 1];
                     const int nq = (bend - bbeg) >> 2;
-                    const i4 *wq = (const i4 *)(smem + L::bw) + (bbeg >> 2) * 8 + ri;
+                    const i4 *wq = (const i4 *)(smem + L::bw) + (bbeg >> 2) * 8 + ri + (b_dense ? ((0x321100 >> (4 * g)) & 15) * 8 : 0);
                     const unsigned char *xb = smem + L::xqT + s * 384;
                     if (b_dense) {
                         // all 96 input blocks in order: 24 quads, software-pipelined in batches of 4 quads
