@@ -156,7 +156,8 @@ template <int S> struct Lds {
     static constexpr int bstart = bbias + 2 * RB * 4;               // [8] i32
     static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
-    static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
+    static constexpr int rowtab = boff + 1216;                      // [3][512] i32: the rows a lane owns (-1: none) -- an LDS read where a VGPR would be spilled to scratch
+    static constexpr int bw     = rowtab + 3 * LPCN_WG_THREADS * 4; // [nb_b padded][8][4] f32
     static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 28 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
     static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }                          // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
@@ -349,7 +350,16 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // ------------------------------------------------------------------ resident weights ----
     WT w[NW];
     uint32_t offp[(NW + 1) / 2];
-    int row[3];
+#ifndef LPCN_ROW_LDS
+#define LPCN_ROW_LDS 0          // the lane's row numbers live in LDS (the PARITY float kernels spilled them to scratch and re-read them at every slot boundary)
+#endif
+    int row_reg[3];
+    const int *const sm_row = (const int *)(smem + L::rowtab) + tid0;
+#if LPCN_ROW_LDS
+#define LPCN_ROW(k) (sm_row[(k) * LPCN_WG_THREADS])
+#else
+#define LPCN_ROW(k) (row_reg[k])
+#endif
     {
         const int lane = tid0 & 63, wave = tid0 >> 6;
         const size_t base = (size_t)wave * NW * 64 + lane;
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         }
         const auto *ar = as_global(Ap->a_row);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) row[k] = ar[(wave * 3 + k) * 64 + lane];
+        for (int k = 0; k < 3; ++k) { row_reg[k] = ar[(wave * 3 + k) * 64 + lane]; ((int *)(smem + L::rowtab))[k * LPCN_WG_THREADS + tid0] = row_reg[k]; }
     }
     int b1 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 1]);
     int b2 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 2]);
@@ -411,8 +421,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #define fc_b_g (HOIST ? fc_b_s : as_global(Ap->fc_b))
 #define fc_f_g (HOIST ? fc_f_s : as_global(Ap->fc_f))
     // bit k: this wave owns rows in slot k (wave-uniform)
-    const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row[1] >= 0) != 0ull ? 2 : 0) |
-                                                        (__ballot(row[2] >= 0) != 0ull ? 4 : 0));
+    const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row_reg[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row_reg[1] >= 0) != 0ull ? 2 : 0) |
+                                                        (__ballot(row_reg[2] >= 0) != 0ull ? 4 : 0));
     const bool has2 = (has_slot & 4) != 0;
     // Waves that do not run GRU-B compute the HEAD of their candidate slot's chains (the first `hl` blocks of every
     // row of slot 0, stored end-aligned at items [NW - hl, NW) by model_pack.c) one sample ahead, in GRU-B's shadow, and park
@@ -837,7 +847,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // for all three slots before the wave waits for the indices / the gathered rows.
             float pre_b[3][S] = {}, pre_c[3][S] = {};
             auto row_pre = [&](const int k, const int slot) {
-                int r = row[k];
+                int r = LPCN_ROW(k);
                 LPCN_REMAT_V(r);
                 r = r < 0 ? 0 : r;
                 const int n = r >= 2 * NA ? r - 2 * NA : (r >= NA ? r - NA : r);
@@ -851,7 +861,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             };
             auto row_init = [&](const int k, const int set, const bool to_acc, const bool park = true) {
                 const int slot = k;
-                int r = row[k];
+                int r = LPCN_ROW(k);
                 LPCN_REMAT_V(r);
                 const bool live_row = r >= 0;
                 r = r < 0 ? 0 : r;
@@ -868,7 +878,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
             };
             auto row_swap = [&](const int k_done, const int k_next, const bool store_done = true) {   // finished row out, next row in
-                int r = row[k_done], r2 = row[k_next];
+                int r = LPCN_ROW(k_done), r2 = LPCN_ROW(k_next);
                 LPCN_REMAT_V(r);
                 LPCN_REMAT_V(r2);
                 if (r >= 0 && store_done) {
@@ -880,7 +890,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 for (int s = 0; s < S; ++s) acc[s] = sm_pre[r2 * S + s];
             };
             auto row_store = [&](const int k) {
-                int r = row[k];
+                int r = LPCN_ROW(k);
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
 #pragma unroll
@@ -902,7 +912,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             auto run_head = [&]() __attribute__((always_inline)) {
                 if constexpr (!I8 && !FAST && S == 4 && LPCN_PARITY_MFMA == 2) load_negz();
                 {
-                    int r = row[0];
+                    int r = LPCN_ROW(0);
                     LPCN_REMAT_V(r);
                     r = r < 0 ? 0 : r;
                     const int n = r - 2 * NA;
@@ -928,7 +938,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 };
                 step(step, std::integral_constant<int, J0>{});
                 {                                            // park the partial sums as they are (no final scaling)
-                    int r = row[0];
+                    int r = LPCN_ROW(0);
                     LPCN_REMAT_V(r);
                     if (r >= 0) {
 #pragma unroll
@@ -950,7 +960,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 row_init(2, 1, false);
                 row_init(0, 2, true);
             } else {
-                int r = row[0];
+                int r = LPCN_ROW(0);
+                LPCN_REMAT_V(r);
                 r = r < 0 ? 0 : r;
                 const int n = r - 2 * NA;
                 const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
@@ -1027,7 +1038,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 row_store(2);
             }
             if (jmode) {                                     // input part of the candidate rows of slot 0
-                int r = row[0];
+                int r = LPCN_ROW(0);
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
                     const int n = r - 2 * NA;
@@ -1048,7 +1059,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_PROF(0);
             if (tracing) {                                                     // tests: recurrent pre-activations of stream 0
                 LPCN_GLOBAL float *d = as_global_rw(Ap->dbg) + ((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 448;
-                for (int i = tid0; i < RA; i += LPCN_WG_THREADS) d[i] = sm_pre[i * S];
+                int t_ = tid0;
+                LPCN_REMAT_V(t_);                            // (otherwise the LDS address is hoisted out of the sample loop and spilled)
+                for (int i = t_; i < RA; i += LPCN_WG_THREADS) d[i] = sm_pre[i * S];
             }
 
             int tid = tid0;
@@ -1513,9 +1526,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (gate_wave) {
                 // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
                 const float sg = act_sigmoid<FAST>(zrh + rec, sm_tansig);
-                const float r_gate = __shfl(sg, 16 + (lane & 15));
+                // (ds_bpermute with an index formed from the re-materialised lane id: __shfl builds its own lane id, which the compiler
+                // hoists out of the sample loop and spills -- a scratch load in front of GRU-B's gates)
+                const float r_gate = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 + (lane & 15)) << 2, __builtin_bit_cast(int, sg)));
                 const float hc = act_tanh<FAST>(zrh + rec * r_gate, sm_tansig);
-                const float hc_i = __shfl(hc, 32 + (lane & 15));
+                const float hc_i = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((32 + (lane & 15)) << 2, __builtin_bit_cast(int, hc)));
                 if (lane < NB) {
                     const float hold = sm_hB[s * NB + lane];
                     const float hnew = sg * hold + (1.f - sg) * hc_i;
