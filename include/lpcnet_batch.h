@@ -100,6 +100,10 @@ LPCNET_EXPORT int lpcnet_batch_import_state(LPCNetBatch *b, int stream, const LP
 /* Tuning / introspection */
 LPCNET_EXPORT int lpcnet_batch_set_streams_per_workgroup(LPCNetBatch *b, int s);      /* 1, 2, 4; 0 = auto */
 LPCNET_EXPORT int lpcnet_batch_get_streams_per_workgroup(const LPCNetBatch *b);
+/* Streams per workgroup are measured on the batch itself (PARITY arithmetic; FAST takes a table value so that its output
+ * never depends on timing): lpcnet_batch_tune() does it now, on the engine's own stream (~10 ms).  Without it the first
+ * host-pointer call measures; the enqueue-only *_device calls on a caller's stream never do (they use the table value). */
+LPCNET_EXPORT int lpcnet_batch_tune(LPCNetBatch *b);
 LPCNET_EXPORT int lpcnet_batch_enable_timing(LPCNetBatch *b, int on);
 LPCNET_EXPORT int lpcnet_batch_last_timing(LPCNetBatch *b, float *ms_sample_kernel, float *ms_frame_kernels);
 LPCNET_EXPORT const char *lpcnet_batch_last_error(void);

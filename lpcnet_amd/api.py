@@ -102,6 +102,7 @@ def load_library():
     L.lpcnet_batch_import_state.argtypes = [vp, C.c_int, vp]
     L.lpcnet_batch_set_streams_per_workgroup.argtypes = [vp, C.c_int]
     L.lpcnet_batch_get_streams_per_workgroup.argtypes = [vp]
+    L.lpcnet_batch_tune.argtypes = [vp]
     L.lpcnet_batch_enable_timing.argtypes = [vp, C.c_int]
     L.lpcnet_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.lpcnet_batch_last_error.restype = C.c_char_p
@@ -365,6 +366,10 @@ class LPCNetBatch:
 
     def set_state(self, stream: int, st: StreamState):
         self._chk(self.L.lpcnet_batch_set_raw_state(self.p, stream, C.byref(st)), "set_state")
+
+    def tune(self):
+        """measure the streams per workgroup now, on the engine's own stream (the enqueue-only device-pointer calls never do)"""
+        self._chk(self.L.lpcnet_batch_tune(self.p), "tune")
 
     @property
     def streams_per_workgroup(self):

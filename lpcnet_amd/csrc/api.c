@@ -886,6 +886,7 @@ int lpcnet_batch_import_state(LPCNetBatch *b, int stream, const LPCNetState *st)
 }
 
 int lpcnet_batch_set_streams_per_workgroup(LPCNetBatch *b, int spw) { NEED_MODEL(b); EACH_SHARD(lpcn_batch_dev_set_streams_per_wg(s->dev, spw)); }
+int lpcnet_batch_tune(LPCNetBatch *b) { NEED_MODEL(b); EACH_SHARD(lpcn_batch_dev_tune(s->dev)); }
 int lpcnet_batch_get_streams_per_workgroup(const LPCNetBatch *b) { return b && b->n_shards && b->sh[0].dev ? lpcn_batch_dev_streams_per_wg(b->sh[0].dev) : 0; }
 int lpcnet_batch_enable_timing(LPCNetBatch *b, int on) { NEED_MODEL(b); EACH_SHARD(lpcn_batch_dev_enable_timing(s->dev, on)); }
 /* kernel milliseconds of the most recent run: the slowest shard */

@@ -542,11 +542,16 @@ static int launch_frames(lpcn_batch_dev *b, hipStream_t st, const float *d_feat,
 // is ~4 % of a two-frame launch and grows with the workgroup count, which biased a plain two-frame timing against the
 // two-workgroups-per-CU form of the int8 kernel).  ~9 launches, ~12 ms, once per batch and arithmetic flavour;
 // LPCNET_HIP_NO_AUTOTUNE=1 keeps the table value.
+// Round 4: (a) the FAST flavour is never timed -- its float kernels switch GRU-B's algorithm with S (matrix-pipe GEMM at S >= 2,
+// fused DPP chains at S = 1: different summation orders), so a measured S would make FAST output depend on timing noise;
+// it takes the table's value, a pure function of (blob kind, stream count, device).  (b) the measurement is the best of
+// three timing pairs.  (c) it never runs inside the enqueue-only device-pointer calls on a caller's stream (those take the
+// table's value unless lpcnet_batch_tune() has been called): it allocates, synchronises and would break stream capture.
 static int autotune_streams_per_wg(lpcn_batch_dev *b, hipStream_t st)
 {
     b->tuned = true;
     const char *off = getenv("LPCNET_HIP_NO_AUTOTUNE");
-    if ((off && *off == '1') || b->n < 2) return 0;           // (one stream: one workgroup whatever S is)
+    if ((off && *off == '1') || b->n < 2 || b->e->fast) return 0;     // (one stream: one workgroup whatever S is)
     const int nf = 5 < b->max_chunk ? 5 : b->max_chunk;
     int rc = 0;
     lpcn_stream_state *saved = nullptr;
@@ -567,18 +572,18 @@ static int autotune_streams_per_wg(lpcn_batch_dev *b, hipStream_t st)
     float best_ms = -1.f;
     for (int S = 1; S <= 4; S *= 2) {
         b->S = S; b->pack2 = use_pack2(b->e, b->n, S);
-        float ms = 0.f, ms1 = 0.f;
-        for (int pass = 0; pass < 3 && !rc; ++pass) {          // warm-up (1 frame), 1 frame, nf frames
-            const int k = pass == 2 ? nf : 1;
+        float ms = -1.f, ms1 = 0.f;
+        for (int pass = 0; pass < 7 && !rc; ++pass) {          // warm-up (1 frame), then three pairs of (1 frame, nf frames): the smallest difference
+            const int k = (pass && !(pass & 1)) ? nf : 1;
             float t = 0.f;
             if (hipEventRecord(b->ev[1], st) != hipSuccess) rc = LPCN_E_HIP;
             if (!rc) rc = launch_sample(b, st, pcm, (size_t)nf * LPCN_FRAME_SIZE, k, 0, true);
             if (!rc && (hipEventRecord(b->ev[2], st) != hipSuccess || hipEventSynchronize(b->ev[2]) != hipSuccess ||
                         hipEventElapsedTime(&t, b->ev[1], b->ev[2]) != hipSuccess)) rc = LPCN_E_HIP;
-            if (pass == 1) ms1 = t; else ms = t;
+            if (pass & 1) ms1 = t;
+            else if (pass) { const float d = nf > 1 ? t - ms1 : t; if (ms < 0.f || d < ms) ms = d; }      // nf - 1 frames in steady state
         }
         if (rc) break;
-        if (nf > 1) ms -= ms1;                                  // nf - 1 frames in steady state
         if (best_ms < 0.f || ms < best_ms) { best_ms = ms; best = S; }
     }
     // the measurement ran on the real state: put it back
@@ -587,6 +592,19 @@ static int autotune_streams_per_wg(lpcn_batch_dev *b, hipStream_t st)
     if (rc) { b->S = keepS; b->pack2 = keepP; return done(rc); }
     b->S = best; b->pack2 = use_pack2(b->e, b->n, best);
     return done(0);
+}
+
+// lpcnet_batch_tune(): measure now, on the engine's own stream (e.g. right after lpcnet_batch_load_model), so that the first
+// synthesize call -- in particular an enqueue-only one on a caller's stream -- carries no measurement
+extern "C" int lpcn_batch_dev_tune(lpcn_batch_dev *b)
+{
+    DeviceGuard guard(b->e->device);
+    if (!b->S_auto) return 0;
+    hipStream_t st = b->e->stream;
+    int rc = order_begin(b, st);
+    if (rc) return rc;
+    if ((rc = autotune_streams_per_wg(b, st))) return rc;
+    return order_end(b, st);
 }
 
 extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, int feat_stride,
@@ -599,7 +617,7 @@ extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, in
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->e->stream;
     float tf = 0.f, ts = 0.f;
     { int rco = order_begin(b, st); if (rco) return rco; }
-    if (b->S_auto && !b->tuned) { int rct = autotune_streams_per_wg(b, st); if (rct) return rct; }
+    if (b->S_auto && !b->tuned && st == b->e->stream) { int rct = autotune_streams_per_wg(b, st); if (rct) return rct; }      // (never on a caller's stream)
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
         if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));

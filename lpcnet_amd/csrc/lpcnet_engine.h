@@ -128,6 +128,7 @@ int  lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n_streams, 
 void lpcn_batch_dev_destroy(lpcn_batch_dev *b);
 int  lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count);           /* lpcnet_reset   */
 int  lpcn_batch_dev_get_state(lpcn_batch_dev *b, int stream, lpcn_stream_state *host);
+int  lpcn_batch_dev_tune(lpcn_batch_dev *b);              /* measure the streams per workgroup now, on the engine's own stream */
 int  lpcn_batch_dev_set_state(lpcn_batch_dev *b, int stream, const lpcn_stream_state *host);
 int  lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b);
 int  lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s);              /* 1,2,4 (0=auto) */

@@ -423,6 +423,63 @@ int orc_sample_mdense(const orc_model *m, const float *input, unsigned *rng)
     return val;
 }
 
+/* ---- the engine's "fp16 dual FC" sub-option (BASELINE.json config 4; lpcnet_batch_set_fast(b, 2)) -----------------------
+ * The reference has no fp16 arithmetic; this is the oracle-side statement of what the option computes, so that the engine's
+ * tree can be checked against something other than itself: dual-FC weights and the GRU-B state rounded to binary16
+ * (round to nearest even), products exact (11 x 11 significand bits fit fp32), sums accumulated in fp32 in index order, two
+ * terms per step -- the hardware's v_dot2_f32_f16 does not document whether the two products of a step are summed exactly
+ * before the accumulator is added (variant 1) or added one after the other with an fp32 rounding each (variant 0): both
+ * are provided, the test's tolerance covers their difference.  tanh is evaluated in double (the engine's FAST flavour
+ * uses the hardware exponential and reciprocal, a few 1e-7 off).  logits[b] = the logit of the node on `path` at level b. */
+static float orc_f16_round(float x)
+{
+    union { float f; unsigned u; } v, r;
+    v.f = x;
+    const unsigned sign = v.u & 0x80000000u, a = v.u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return x;                              /* inf / nan */
+    if (a >= 0x477FF000u) { r.u = sign | 0x7F800000u; return r.f; }   /* rounds to >= 65520: overflow to inf */
+    if (a < 0x33000000u) { r.u = sign; return r.f; }            /* < 2^-25: rounds to zero */
+    if (a < 0x38800000u) {                                       /* subnormal half: multiples of 2^-24 */
+        const double q = (double)fabsf(x) * 16777216.0;         /* / 2^-24 */
+        double fl = floor(q), fr = q - fl;
+        if (fr > 0.5 || (fr == 0.5 && ((long long)fl & 1))) fl += 1.0;
+        r.f = (float)(fl / 16777216.0);
+        r.u |= sign;
+        return r.f;
+    }
+    {                                                            /* normal: keep 10 fraction bits, RNE on the 13 dropped */
+        unsigned m = a, rem = m & 0x1FFFu;
+        m &= ~0x1FFFu;
+        if (rem > 0x1000u || (rem == 0x1000u && (m & 0x2000u))) m += 0x2000u;
+        r.u = sign | m;
+        return r.f;
+    }
+}
+
+float orc_f16(float x) { return orc_f16_round(x); }         /* (exported for the test that pins it to IEEE binary16) */
+
+void orc_mdense_f16_path(const orc_model *m, const float *input, int path, int variant, float *logits)
+{
+    float h[N_B];
+    int b, j, c;
+    for (j = 0; j < N_B; j++) h[j] = orc_f16_round(input[j]);
+    for (b = 0; b < 8; b++) {
+        const int i = (1 << b) | (path >> (8 - b));
+        float s[2];
+        for (c = 0; c < 2; c++) {
+            const float *w = m->fc_w + i * 2 * N_B + c * N_B;
+            float acc = m->fc_b[c * 256 + i];
+            for (j = 0; j < N_B; j += 2) {
+                const float w0 = orc_f16_round(w[j]), w1 = orc_f16_round(w[j + 1]);
+                if (variant) acc = (float)((double)acc + ((double)w0 * h[j] + (double)w1 * h[j + 1]));
+                else { acc = acc + w0 * h[j]; acc = acc + w1 * h[j + 1]; }
+            }
+            s[c] = m->fc_f[c * 256 + i] * (float)tanh((double)acc);
+        }
+        logits[b] = s[0] + s[1];
+    }
+}
+
 /* ======================================================================================
  * per-stream state and the two rates
  * ====================================================================================== */

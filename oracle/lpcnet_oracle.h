@@ -71,6 +71,10 @@ void orc_gru_a_input(const orc_model *m, float *out, const float *cond, int sig,
 void orc_sparse_gru_a(const orc_model *m, float *state, const float *input);
 void orc_gru_b(const orc_model *m, const float *cond_b, float *state, const float *input);
 int  orc_sample_mdense(const orc_model *m, const float *input, unsigned *rng4);
+/* the engine's fp16 dual-FC sub-option restated (no reference counterpart): logits[8] of the nodes on the 8-bit `path`;
+ * variant 0 / 1 = the two possible rounding orders of a v_dot2_f32_f16 step (see lpcnet_oracle.c) */
+float orc_f16(float x);                                     /* float -> binary16 -> float, round to nearest even */
+void orc_mdense_f16_path(const orc_model *m, const float *input, int path, int variant, float *logits);
 
 /* scalar helpers */
 int   orc_lin2ulaw(float x);                                /* src/common.h:47-58 */

@@ -63,6 +63,10 @@ def lib():
     L.orc_sparse_gru_a.argtypes = [vp, _f32p, _f32p]
     L.orc_gru_b.argtypes = [vp, _f32p, _f32p, _f32p]
     L.orc_sample_mdense.argtypes = [vp, _f32p, _u32p]
+    L.orc_mdense_f16_path.argtypes = [vp, _f32p, C.c_int, C.c_int, _f32p]
+    L.orc_mdense_f16_path.restype = None
+    L.orc_f16.argtypes = [C.c_float]
+    L.orc_f16.restype = C.c_float
     L.orc_lin2ulaw.argtypes = [C.c_float]
     L.orc_ulaw2lin.argtypes = [C.c_int]
     L.orc_ulaw2lin.restype = C.c_float
@@ -104,6 +108,12 @@ class OracleModel:
 
     def new_state(self):
         return OracleState(self)
+
+    def mdense_f16_path(self, gru_b: np.ndarray, path: int, variant: int = 0) -> np.ndarray:
+        """logits of the 8 tree nodes on `path` in the engine's fp16 dual-FC arithmetic (oracle-side restatement)"""
+        out = np.zeros(8, np.float32)
+        self.L.orc_mdense_f16_path(self.p, np.ascontiguousarray(gru_b, np.float32), int(path), int(variant), out)
+        return out
 
 
 class OracleState:

@@ -36,13 +36,21 @@ def forced_states(blob, feats, pcm, fast, S):
     return ga, gb
 
 
-@pytest.mark.parametrize("flavour,S,kw", [("float", 4, {}), ("float", 2, {}), ("float", 1, {}), ("int8", 4, {}), ("int8", 2, {}),
+@pytest.mark.parametrize("flavour,S,kw", [("float", 4, {}), ("float", 2, {}), ("float", 1, {}), ("int8", 4, {}), ("int8", 2, {}), ("int8", 1, {}),
                                           ("float", 4, dict(grub_density=0.4)), ("float", 2, dict(grub_density=0.4)),
-                                          ("int8", 4, dict(grub_density=0.4))],
-                         ids=["f32-S4", "f32-S2", "f32-S1", "int8-S4", "int8-S2", "f32-S4-sparseB", "f32-S2-sparseB", "int8-S4-sparseB"])
+                                          ("int8", 4, dict(grub_density=0.4)),
+                                          ("float", 4, dict(densities=(0.02, 0.02, 0.1))), ("float", 4, dict(densities=(0.07, 0.07, 0.25))),
+                                          ("float", 2, dict(densities=(0.07, 0.07, 0.25))),
+                                          ("int8", 4, dict(densities=(0.07, 0.07, 0.25))), ("int8", 2, dict(densities=(0.07, 0.07, 0.25))),
+                                          ("int8", 2, dict(densities=(0.02, 0.02, 0.1)))],
+                         ids=["f32-S4", "f32-S2", "f32-S1", "int8-S4", "int8-S2", "int8-S1", "f32-S4-sparseB", "f32-S2-sparseB", "int8-S4-sparseB",
+                              "f32-S4-sparseA", "f32-S4-denseA", "f32-S2-denseA", "int8-S4-denseA", "int8-S2-denseA", "int8-S2-sparseA"])
 def test_fast_teacher_forced_inside_reference_simd_envelope(flavour, S, kw, hip_lib):
     """(S = 2 runs the matrix-pipe items with two dead accumulator columns; a block-sparse GRU-B switches the
-    split / dense fast paths of GRU-B off; 16 streams x 100 frames = every lane position of four workgroups)"""
+    split / dense fast paths of GRU-B off; 16 streams x 100 frames = every lane position of four workgroups.  VERDICT r3: the
+    other register-resident variants FAST instantiates -- sparser / denser GRU-A = other items-per-lane kernels, float and
+    int8 -- and int8 at one stream per workgroup; the envelope itself was generated on the default model, a denser GRU-A sums
+    more terms per row, hence the wider factor there)"""
     env = ENVELOPE[flavour]
     p99_a, worst_a, worst_b = env["gru_a"]["p99"], env["gru_a"]["worst"], env["gru_b"]["worst"]
     blob = synth.blob_bytes(synth.make_model(flavour=flavour, **kw))
@@ -59,8 +67,9 @@ def test_fast_teacher_forced_inside_reference_simd_envelope(flavour, S, kw, hip_
     assert np.abs(ga_p[live]).max() > 0.3                    # the states are alive
     assert da.max() > 0 or flavour == "float"                # FAST is a different arithmetic (float FMA may round alike on a grid model)
     # (100 frames here against 200 in the envelope: 1.25 x covers the sampling noise of a p99 / maximum of a chaotic quantity)
-    assert np.percentile(da, 99) <= 1.25 * p99_a and da.max() <= 1.25 * worst_a, (np.percentile(da, 99), da.max(), env)
-    assert db.max() <= 1.25 * worst_b, (db.max(), env)
+    slack = 2.0 if "densities" in kw and kw["densities"][2] > 0.2 else 1.25
+    assert np.percentile(da, 99) <= slack * p99_a and da.max() <= slack * worst_a, (np.percentile(da, 99), da.max(), env)
+    assert db.max() <= slack * worst_b, (db.max(), env)
     if flavour == "float":                                  # FMA only changes last bits: far inside the AVX2 build's own drift
         assert da.max() <= 0.1 * p99_a
     # forcing all 160 samples must return them untouched, exactly like PARITY does
@@ -108,32 +117,47 @@ def _tree_decisions(blob, feats, pcm, fast):
 
 
 @pytest.mark.parametrize("flavour", ["float", "int8"])
-def test_fp16_dual_fc_decision_flips(flavour, hip_lib):
-    """BASELINE.json config 4 names an fp16 dual FC.  It is a FAST sub-option (lpcnet_batch_set_fast(b, 2)); the reference
-    has nothing to pin it to, so it is measured against FAST with the fp32 tree, teacher-forced on the same signal (same
-    GRU-B states up to FAST's own last-bit effects, same thresholds): the tree decision may change only where a logit
-    sits within fp16 rounding of its threshold.  For scale, the share of decisions FAST itself changes against PARITY is
-    measured the same way."""
+def test_fp16_dual_fc_against_the_oracle_restatement(flavour, hip_lib):
+    """BASELINE.json config 4 names an fp16 dual FC: a FAST sub-option (lpcnet_batch_set_fast(b, 2)).  The reference has no fp16
+    arithmetic, so the pin is the oracle-side restatement of the option (oracle/lpcnet_oracle.c: orc_mdense_f16_path --
+    weights and GRU-B state rounded to binary16, exact products, fp32 sums in index order): teacher-forced on one stream,
+    every sample's tree decision of the ENGINE is replayed on the oracle from the GRU-B state the engine drew it from
+    (the trace) and the thresholds of the reference's own RNG stream; at every tree level the engine's bit must be the
+    oracle's wherever the oracle's logit is farther from the threshold than TOL.  TOL covers what the restatement leaves
+    open: the rounding order inside one v_dot2_f32_f16 step (both orders are evaluated) and FAST's hardware exp / rcp in
+    tanh (a few 1e-7 relative) times the node's output factors."""
+    from oracle import orc
     blob = synth.blob_bytes(synth.make_model(flavour=flavour))
-    T = 60
+    om = orc.OracleModel(blob)
+    L = orc.lib()
+    T = 40
     feats = synth.make_features(9100, T)[None]
     ref = api.LPCNetBatch(1, blob)
     pcm = ref.synthesize(feats)
     ref.close()
-    d_par, hb_par = _tree_decisions(blob, feats, pcm, 0)
-    d_fast, hb_fast = _tree_decisions(blob, feats, pcm, 1)
-    d_f16, hb_f16 = _tree_decisions(blob, feats, pcm, 2)
-    n = d_par.size
-    assert n == (T - 2) * 160 and np.unique(d_par).size > 20           # a live sampler, not a stuck one
-    assert np.array_equal(hb_fast, hb_f16)                               # the fp16 tree changes nothing upstream of the tree
-    flips_fast = float((d_fast != d_par).mean())
-    flips_f16 = float((d_f16 != d_fast).mean())
-    # fp16 weights and state perturb a logit by ~1e-3 of its range: a few per cent of the decisions sit that close to a threshold
-    assert flips_f16 < 0.06, (flips_f16, flips_fast)
-    # and a changed decision is a NEIGHBOURING one far more often than not (the low bits of the mu-law code)
-    moved = np.abs(d_f16 - d_fast)[d_f16 != d_fast]
-    assert moved.size == 0 or np.median(moved) <= 8, (np.median(moved), moved[:20])
-    print("decision flips: FAST vs PARITY %.4f, fp16 tree vs FAST %.4f (%d samples)" % (flips_fast, flips_f16, n))
+    d_f16, hb = _tree_decisions(blob, feats, pcm, 2)
+    n = d_f16.size
+    assert n == (T - 2) * 160 and np.unique(d_f16).size > 20             # a live sampler, not a stuck one
+    rng = np.zeros(4, np.uint32)
+    L.orc_kiss99_srand(rng, b"LPCNet", 6)                                 # src/lpcnet.c:179 reseeds at reset; two words per live sample
+    TOL = 2e-4
+    undecided = checked = 0
+    for k in range(n):
+        r0, r1 = L.orc_kiss99_rand(rng), L.orc_kiss99_rand(rng)
+        thr = [L.orc_logit_table((r0 >> (8 * b)) & 0xFF) for b in range(4)] + [L.orc_logit_table((r1 >> (8 * b)) & 0xFF) for b in range(4)]
+        path = int(d_f16[k])
+        la, lb = om.mdense_f16_path(hb[k], path, 0), om.mdense_f16_path(hb[k], path, 1)
+        assert np.abs(la - lb).max() <= TOL / 4, (k, la, lb)               # the two rounding orders agree far inside the tolerance
+        for b in range(8):
+            bit = (path >> (7 - b)) & 1
+            margin = min(abs(la[b] - thr[b]), abs(lb[b] - thr[b]))
+            if margin > TOL * max(1.0, abs(float(la[b]))):
+                assert bit == int(thr[b] < la[b]), (k, b, path, la[b], thr[b])
+                checked += 1
+            else:
+                undecided += 1
+    assert checked > 7.9 * n and undecided < 0.01 * n, (checked, undecided, n)
+    print("fp16 tree vs oracle restatement: %d level decisions equal, %d within the tolerance band (%d samples)" % (checked, undecided, n))
     # free running: sane statistics
     b = api.LPCNetBatch(4, blob)
     b.set_fast(2)
@@ -144,3 +168,24 @@ def test_fp16_dual_fc_decision_flips(flavour, hip_lib):
     b.close()
     r = out[:, 320:].astype(np.float64).std() / par[:, 320:].astype(np.float64).std()
     assert np.all(out[:, :320] == 0) and 0.7 < r < 1.4, r
+
+
+@pytest.mark.parametrize("flavour,opt", [("float", 1), ("int8", 1), ("int8", 2)])
+def test_fast_output_does_not_depend_on_timing(flavour, opt, hip_lib):
+    """ FAST float switches GRU-B's algorithm with the streams per workgroup, so that value must not come out of
+    a timing measurement: two fresh FAST batches -- one of them tuned explicitly -- choose the same S by rule and return
+    identical PCM; the PARITY flavour may measure (all its S are bit-identical anyway)."""
+    blob = synth.blob_bytes(synth.make_model(flavour=flavour))
+    n, T = 512, 6
+    feats = np.stack([synth.make_features(9300 + (s % 16), T) for s in range(n)])
+    outs, spw = [], []
+    for tuned in (False, True, False):
+        b = api.LPCNetBatch(n, blob)
+        b.set_fast(opt)
+        if tuned:
+            b.tune()
+        outs.append(b.synthesize(feats))
+        spw.append(b.streams_per_workgroup)
+        b.close()
+    assert spw[0] == spw[1] == spw[2], spw
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

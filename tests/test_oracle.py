@@ -186,3 +186,17 @@ def test_end2end_variant_matches_reference(blob_f32):
     got = orc.OracleModel(blob_f32, end2end=True).new_state().synthesize(f)
     assert np.array_equal(got, want)
     assert not np.array_equal(got, orc.OracleModel(blob_f32).new_state().synthesize(f))
+
+
+def test_fp16_restatement_rounds_like_ieee_binary16():
+    """the oracle-side statement of the engine's fp16 dual-FC option rounds to binary16 exactly like IEEE (numpy float16):
+    normals, subnormals, ties, overflow"""
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s for s in (1e-8, 1e-6, 6e-5, 1e-3, 1.0, 300.0, 7e4)])
+    ties = (np.arange(1, 2000, dtype=np.float32) * 2 + 1) * np.float32(2.0 ** -11)       # exactly half way between two halves near 1..2
+    xs = np.concatenate([xs, ties + 1.0, -(ties + 1.0), np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25], np.float32)])
+    got = np.array([L.orc_f16(float(x)) for x in xs], np.float32)
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
