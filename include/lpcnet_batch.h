@@ -65,7 +65,11 @@ LPCNET_EXPORT int lpcnet_batch_synthesize_preload(LPCNetBatch *b, const float *f
  *   n_samples[s] in 1..160; the first preload[s] <= n_samples[s] samples of pcm[s] are imposed on the synthesis filter
  *   (teacher forcing, src/lpcnet.c:256-259) and returned unchanged; samples n_samples[s]..159 of pcm[s] are not touched.
  * Streams with equal (mode, n_samples, preload) run together; results are bit-identical to driving each stream alone through
- * the single-stream entry points.  Meant for occasional use (it compacts and scatters the groups), not for throughput. */
+ * the single-stream entry points.  Meant for occasional use (it compacts and scatters the groups), not for throughput.
+ * A mode-2 step needs a mode-1 step of THIS call as the stream's most recent frame step: the products are kept per stream
+ * only here, so after lpcnet_batch_synthesize* / _decode* / a reset / a state import the call returns -4 (bad argument) for
+ * such a stream (checked for all streams before anything runs).  The call is not atomic across groups: if a later group
+ * fails on the device, earlier groups of the same call have already advanced. */
 LPCNET_EXPORT int lpcnet_batch_synthesize_step(LPCNetBatch *b, const float *features, int feat_stride, short *pcm,
                                                const int *n_samples, const int *preload, const int *mode);
 /* Codec path: packets [n_streams][n_packets][8] -> pcm [n_streams][n_packets*640] (lpcnet_decode per stream) */

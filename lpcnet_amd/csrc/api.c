@@ -206,9 +206,12 @@ static int packet_to_features(float feat[4][NB_TOTAL_FEATURES], float *vq_mem, c
 /* ---- model registry for the single-stream API ------------------------------------------------
  * One slot per distinct weight blob (the registry keeps its own copy: dedupe compares the bytes, and a slot can
  * rebuild its device side at any time).  lpcnet_hip_shutdown() only releases the device resources, so a state bound
- * before the shutdown simply re-creates them at its next call.  When all MAX_MODELS slots are taken, binding another
- * blob evicts the least recently used slot that is not in a call (states are PODs that may be copied or dropped at
- * will, so there is nothing to count references with); a state still holding the evicted handle stops with a message. */
+ * before the shutdown simply re-creates them at its next call.  Two limits (round 4): at most MAX_RESIDENT slots hold a
+ * device side -- materialising one more releases the device side of the least recently used idle slot, whose handle and
+ * blob copy stay valid (its states re-create it transparently at their next call, like after a shutdown) -- and MAX_MODELS
+ * slots in all (the handle's low byte).  Only when that many DISTINCT blobs are bound does binding another one evict a slot
+ * altogether (states are PODs that may be copied or dropped at will, so there is nothing to count references with); a
+ * state still holding such a handle stops with a message. */
 typedef struct {
     int used;
     unsigned gen;                     /* bumped when the slot is evicted: a state's handle carries the generation it was bound with */
@@ -222,7 +225,8 @@ typedef struct {
     lpcn_stream_state cached;
     pthread_mutex_t run_lock;         /* one device round trip at a time per model */
 } registry_entry;
-#define MAX_MODELS 16
+#define MAX_MODELS 256
+#define MAX_RESIDENT 16
 static registry_entry g_reg[MAX_MODELS];
 static int g_device = -1;             /* device of the single-stream API: lpcnet_hip_set_device(), $LPCNET_HIP_DEVICE, else 0 */
 static int g_default_model = -1;      /* handle of the process-default model, -1 = not resolved yet */
@@ -255,10 +259,29 @@ int lpcnet_hip_set_device(int device)
     return 0;
 }
 
-/* (g_lock held) device side of a slot, created on first use and after lpcnet_hip_shutdown() */
+/* (g_lock held) device side of a slot, created on first use, after lpcnet_hip_shutdown() and after it was released to make
+ * room: the number of resident device sides is bounded, the least recently used idle one goes first */
 static int registry_materialize(registry_entry *r)
 {
     if (r->dev) return 0;
+    {
+        int resident = 0, victim = -1;
+        for (int i = 0; i < MAX_MODELS; i++) if (g_reg[i].used && g_reg[i].dev) resident++;
+        while (resident >= MAX_RESIDENT) {
+            victim = -1;
+            for (int i = 0; i < MAX_MODELS; i++)
+                if (g_reg[i].used && g_reg[i].dev && &g_reg[i] != r && __atomic_load_n(&g_reg[i].pins, __ATOMIC_SEQ_CST) == 0 &&
+                    (victim < 0 || g_reg[i].last_use < g_reg[victim].last_use)) victim = i;
+            if (victim < 0 || pthread_mutex_trylock(&g_reg[victim].run_lock) != 0) break;       /* everything resident is in a call: go over the limit for now */
+            registry_entry *v = &g_reg[victim];
+            lpcn_batch_dev_destroy(v->dev);
+            lpcn_engine_destroy(v->engine);
+            __atomic_store_n(&v->dev, (lpcn_batch_dev *)NULL, __ATOMIC_SEQ_CST);
+            v->engine = NULL; v->cache_valid = 0;
+            pthread_mutex_unlock(&v->run_lock);
+            resident--;
+        }
+    }
     lpcn_model_host m;
     if (lpcn_model_parse(&m, r->blob, r->len) != 0) { set_err("malformed or incomplete DNNw weight blob"); return -1; }
     lpcn_engine *e = NULL;

@@ -66,6 +66,7 @@ struct lpcn_batch_dev {
     lpcn_stream_state *d_state_tmp = nullptr;   // per-stream-arguments step (lpcn_batch_dev_step_host): the compacted group's states
     int *d_map = nullptr;              //   ... and its stream indices
     float *d_keep_a = nullptr, *d_keep_b = nullptr, *d_keep_lpc = nullptr;   //   ... and every stream's most recent frame products
+    std::vector<char> keep_ok;         //   ... which exist only for streams whose last frame step went through the step call (mode 1)
     float *d_hmir = nullptr;           // [stream slot][384] GRU-A state mirror read by GRU-B through the scalar cache (sample_kernel.hip.h: gb_scalar)
     unsigned char *d_packets = nullptr;
     size_t packets_cap = 0;
@@ -431,6 +432,7 @@ static void host_reset_state(lpcn_stream_state *st)
 
 extern "C" int lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count)
 {
+    if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (lpcn_batch_dev_step_host's per-stream frame products are stale now)
     if (first < 0 || count < 0 || first + count > b->n) { snprintf(g_err, sizeof(g_err), "reset range"); return LPCN_E_ARG; }
     DeviceGuard guard(b->e->device);
     std::vector<lpcn_stream_state> h(count);
@@ -451,6 +453,7 @@ extern "C" int lpcn_batch_dev_get_state(lpcn_batch_dev *b, int s, lpcn_stream_st
 }
 extern "C" int lpcn_batch_dev_set_state(lpcn_batch_dev *b, int s, const lpcn_stream_state *host)
 {
+    if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (lpcn_batch_dev_step_host's per-stream frame products are stale now)
     if (s < 0 || s >= b->n) { snprintf(g_err, sizeof(g_err), "stream index"); return LPCN_E_ARG; }
     DeviceGuard guard(b->e->device);
     { int rcw = wait_all(b); if (rcw) return rcw; }
@@ -617,6 +620,7 @@ extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, in
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->e->stream;
     float tf = 0.f, ts = 0.f;
     { int rco = order_begin(b, st); if (rco) return rco; }
+    if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (the step call's per-stream frame products are stale now)
     if (b->S_auto && !b->tuned && st == b->e->stream) { int rct = autotune_streams_per_wg(b, st); if (rct) return rct; }      // (never on a caller's stream)
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
@@ -711,6 +715,7 @@ extern "C" int lpcn_batch_dev_run_single(lpcn_batch_dev *b, const lpcn_stream_st
 // Codec path: 8-byte packets [stream][packet][8] -> 4 frames each.  Device pointers, work only enqueued.
 extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
 {
+    if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (lpcn_batch_dev_step_host's per-stream frame products are stale now)
     if (n_packets <= 0) { snprintf(g_err, sizeof(g_err), "bad decode arguments"); return LPCN_E_ARG; }
     if (!b->e->has_codebooks) { snprintf(g_err, sizeof(g_err), "no VQ codebooks installed (lpcnet_hip_set_codebooks)"); return LPCN_E_MODEL; }
     DeviceGuard guard(b->e->device);
@@ -754,6 +759,7 @@ extern "C" int lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char
 extern "C" int lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond_a, const float *cond_b,
                                             const float *lpc, short *pcm, int n_frames, int preload)
 {
+    if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (lpcn_batch_dev_step_host's per-stream frame products are stale now)
     if (n_frames <= 0 || preload < 0 || preload > LPCN_FRAME_SIZE) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
     DeviceGuard guard(b->e->device);
     const size_t npcm = (size_t)b->n * n_frames * LPCN_FRAME_SIZE;
@@ -790,6 +796,7 @@ extern "C" int lpcn_batch_dev_run_tail_host(lpcn_batch_dev *b, const float *cond
 extern "C" int lpcn_batch_dev_run_frames_host(lpcn_batch_dev *b, const float *features, int feat_stride,
                                               float *cond_a, float *cond_b, float *lpc, int n_frames)
 {
+    if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (lpcn_batch_dev_step_host's per-stream frame products are stale now)
     if (n_frames <= 0 || feat_stride < LPCN_NB_FEAT) { snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG; }
     DeviceGuard guard(b->e->device);
     const size_t nfeat = (size_t)b->n * n_frames * feat_stride;
@@ -849,6 +856,15 @@ extern "C" int lpcn_batch_dev_step_host(lpcn_batch_dev *b, const float *features
             snprintf(g_err, sizeof(g_err), "stream %d: n_samples must be 1..160 and preload 0..n_samples", s); return LPCN_E_ARG;
         }
     }
+    // a tail-only step continues the frame of the stream's last mode-1 step: the reference's lpcnet_synthesize_tail_impl uses
+    // whatever the last run_frame_network left in the state, but this engine keeps frame products per stream only for
+    // steps that went through this call -- a stream advanced by the ordinary synthesize / decode calls has none
+    if (b->keep_ok.size() != (size_t)b->n) b->keep_ok.assign((size_t)b->n, 0);
+    for (int s = 0; s < b->n; ++s)
+        if (mode[s] == 2 && !b->keep_ok[s]) {
+            snprintf(g_err, sizeof(g_err), "stream %d: a tail-only step (mode 2) needs a preceding frame step (mode 1) of lpcnet_batch_synthesize_step", s);
+            return LPCN_E_ARG;
+        }
     DeviceGuard guard(b->e->device);
     int rc = ensure_staging(b, (size_t)b->n * LPCN_NB_FEAT, (size_t)b->n * LPCN_FRAME_SIZE);
     if (rc) return rc;
@@ -892,6 +908,7 @@ extern "C" int lpcn_batch_dev_step_host(lpcn_batch_dev *b, const float *features
         if (md == 1) {
             rc = launch_frames(b, st, b->d_feat, LPCN_NB_FEAT, (size_t)LPCN_NB_FEAT, 1);
             if (!rc) {      // remember the products per stream (a later tail-only step of the stream uses them)
+                for (int i = 0; i < cnt; ++i) b->keep_ok[(size_t)map[i]] = 1;
                 hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(256), 0, st, b->d_keep_a, (const float *)b->d_cond_a, (const int *)b->d_map, cnt, LPCN_ROWS_A, 1);
                 hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_keep_b, (const float *)b->d_cond_b, (const int *)b->d_map, cnt, LPCN_ROWS_B, 1);
                 hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_keep_lpc, (const float *)b->d_lpc, (const int *)b->d_map, cnt, LPCN_LPC_ORDER, 1);
