@@ -51,8 +51,9 @@ LDS_OPERAND_BYTES_PER_SAMPLE_I8 = 96432 # int8 GRU-A 59 544 + int8 GRU-B 21 912 
 PEAK_FP32_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 vector peak
 PEAK_HBM_GBS = 8000.0
 PEAK_LDS_TBS = 150.0
-MEASURED_FP32_MUL_ADD_TFLOPS = 58.9      # tools/ubench/peaks.hip on this box (profiles/r01_roofline_measured.json): separately
-                                        # rounded multiply + add, no FMA, no packed math -- all the PARITY arithmetic may use
+MEASURED_FP32_MUL_ADD_TFLOPS = 66.9      # tools/ubench/peaks.hip (profiles/r04_roofline_measured.json): separately rounded multiply + add, no FMA,
+                                        # as PACKED math (v_pk_mul_f32 + v_pk_add_f32: 66.9; scalar v_mul_f32 + v_add_f32: 59.5) -- the VALU-only
+                                        # ceiling of the PARITY arithmetic (the kernel also forms exact products on the matrix pipe)
 
 
 def _cpu_worker(args):
@@ -148,6 +149,16 @@ def cpu_baseline(int8_line=False):
     if procs > 2 and procs == cores:
         procs -= 1                                           # leave the quota's last core to this (parent) process
     pins = [allowed[(i * len(allowed)) // procs] for i in range(procs)]       # spread over the mask (distinct physical cores where possible)
+    # the parent (pool bookkeeping, result pickling) moves to a core the pool does not use, so that no worker shares its core with it
+    # (one straggler per int8 pool); restored afterwards
+    spare = [c for c in allowed if c not in pins]
+    old_mask = None
+    if spare:
+        try:
+            old_mask = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, {spare[-1]})
+        except Exception:
+            old_mask = None
     names = {"af": "reference AVX2+FMA float build (oracle/_ref af: -O3 -mavx2 -mfma -DDISABLE_DOT_PROD)",
              "ai": "reference AVX2 int8 build (oracle/_ref ai: -O3 -mavx2 -mfma, the reference's default on x86)",
              "nf": "reference float build with -Ofast -march=native (oracle/_ref nf, README.md:55-57; native to the build host)",
@@ -173,6 +184,11 @@ def cpu_baseline(int8_line=False):
                     "per_core": float(np.median(rates)), "per_core_min": float(min(rates)), "per_core_max": float(max(rates)),
                     "single_process_pinned": n_s / single, "realtime_factor_single": n_s / single / 16000.0,
                     "frames_per_process": frames, "passes": "1 warm-up + best of 3", "pool_wall_s": round(wall, 1), "build": names[fl]}
+    if old_mask is not None:
+        try:
+            os.sched_setaffinity(0, old_mask)
+        except Exception:
+            pass
     main = ("ai" if int8_line else "af") if have else "port"
     frames = flav[main]["frames_per_process"]
     return {"value": flav[main]["value"], "unit": "samples/s", "cores": procs, "kind": kind, "per_core": flav[main]["per_core"],
@@ -320,6 +336,8 @@ def main():
             raise SystemExit(f"bench.py: timed output differs from the CPU oracle on streams {[p for p, g, w in zip(pick, got, want) if not np.array_equal(g, w)]}")
         parity_checked = len(pick)
 
+    if world > 1:
+        dist.barrier()                                       # the last collective: rank 0's CPU baseline below (~90 s) must not leave the other ranks inside one
     samples_per_step = n * F * 160
     value = world * samples_per_step * a.steps / elapsed
     if rank == 0:
@@ -330,7 +348,7 @@ def main():
         op_gbs = kernel_rate * op_bytes / 1e9
         traffic, traffic_src = None, None
         khash = kernel_source_hash()
-        for rnd in ("r03", "r02", "r01"):                    # PMC passes of this command, newest round first
+        for rnd in ("r04", "r03", "r02", "r01"):             # PMC passes of this command, newest round first
             tag = ("_int8" if a.int8 else "") + ("_fast" if a.fast else "")
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic{tag}.json")
             if os.path.exists(tpath) and (n, F) == (STREAMS_PER_GPU, FRAMES_PER_STEP):
@@ -373,7 +391,7 @@ def main():
                          "kernel_source_hash": khash,
                          "valu_fp32": {"achieved_TFLOPs": achieved_tflops, "peak_TFLOPs": PEAK_FP32_TFLOPS,
                                        "frac": achieved_tflops / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE,
-                                       "measured_mul_add_no_fma_TFLOPs": MEASURED_FP32_MUL_ADD_TFLOPS,
+                                       "measured_packed_mul_add_no_fma_TFLOPs": MEASURED_FP32_MUL_ADD_TFLOPS,
                                        "frac_of_measured_no_fma": achieved_tflops / MEASURED_FP32_MUL_ADD_TFLOPS},
                          "l2_gather": {"achieved_GBs": kernel_rate * L2_BYTES_PER_SAMPLE / 1e9, "bytes_per_sample": L2_BYTES_PER_SAMPLE,
                                        "note": "embedding rows + frame products, L2 -> CU; the tables stay L2-resident, this is not HBM traffic"},
@@ -391,7 +409,6 @@ def main():
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -177,5 +177,27 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["parity_checked"] == 8 and "rehearsal" in two
     assert two["config"]["sharding"].startswith("2 x 256")
     # two ranks share one GPU: the aggregate is the one-GPU figure again (256 streams leave most CUs idle, so two such
-    # batches overlap almost perfectly: between 0.9x and 2.2x)
-    assert 0.9 * one["value"] < two["value"] < 2.2 * one["value"], (one["value"], two["value"])
+    # batches overlap almost perfectly).  A sanity bound on a shared GPU, deliberately loose: the structural
+    # asserts above are the gate.
+    assert 0.5 * one["value"] < two["value"] < 3.0 * one["value"], (one["value"], two["value"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", [[], ["--int8"]], ids=["config3-fp32", "config4-int8"])
+def test_bench_eight_rank_shape_rehearsed_on_one_gpu(flag):
+    """BASELINE configs 3 / 4 are 8 192 streams over 8 ranks; nothing of that shape had ever executed.  All eight
+    ranks on the one GPU the box has (gloo control plane, 8 x 1024 distinct streams, every rank its own engine and model
+    copy): the launcher, the rendezvous, the barrier + max-over-ranks timing, rank 0's parity check and JSON line.  No
+    scaling number can come out of eight processes time-sharing one device -- the line says so (`rehearsal`)."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-device", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"] + flag, capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["parity_checked"] == 8 and "rehearsal" in d and d["config"]["sharding"].startswith("8 x 1024")
+    assert d["value"] > 0 and d["scaling"] == "weak"

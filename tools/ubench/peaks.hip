@@ -46,6 +46,28 @@ __global__ __launch_bounds__(512) void valu_mul_add(float *out, int iters)
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// the same arithmetic as packed math: v_pk_mul_f32 + v_pk_add_f32, every half rounded on its own -- PARITY may use it
+// (the no-FMA ceiling has to include it)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(512) void valu_pk_mul_add(float *out, int iters)
+{
+    f2 a[8], h = {out[threadIdx.x] + 1.0001f, out[threadIdx.x] + 0.9999f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (f2){(float)i, (float)i + 0.5f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f2 t;
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(a[i]), "v"(h));
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(t), "v"(h));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i][0] + a[i][1];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 int main()
 {
     hipDeviceProp_t p;
@@ -81,9 +103,14 @@ int main()
     hipLaunchKernelGGL(valu_mul_add, dim3(cus * 4), dim3(512), 0, 0, out, it_v);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     const double valu_tflops = (double)cus * 4 * 512 * 32.0 * it_v / (ms * 1e-3) / 1e12;
+    hipLaunchKernelGGL(valu_pk_mul_add, dim3(cus * 4), dim3(512), 0, 0, out, 10);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(valu_pk_mul_add, dim3(cus * 4), dim3(512), 0, 0, out, it_v);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    const double pk_tflops = (double)cus * 4 * 512 * 32.0 * it_v / (ms * 1e-3) / 1e12;
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, \"lds_read_TBs\": %.1f, \"hbm_copy_TBs\": %.2f, "
-           "\"fp32_mul_add_no_fma_TFLOPs\": %.1f, \"note\": \"measured by tools/ubench/peaks.hip; the guide's peaks (150 TB/s LDS, "
+           "\"fp32_mul_add_no_fma_TFLOPs\": %.1f, \"fp32_packed_mul_add_no_fma_TFLOPs\": %.1f, \"note\": \"measured by tools/ubench/peaks.hip; the guide's peaks (150 TB/s LDS, "
            "8 TB/s HBM, 157.3 TFLOP/s fp32 with packed FMA) are the denominators bench.py uses\"}\n",
-           p.name, cus, p.clockRate / 1000, lds_tbs, hbm_tbs, valu_tflops);
+           p.name, cus, p.clockRate / 1000, lds_tbs, hbm_tbs, valu_tflops, pk_tflops);
     return 0;
 }
