@@ -6,16 +6,20 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-RND=${1:-r03}
+RND=${1:-r04}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 # kernel stats + HBM traffic first: bench.py quotes `roofline.traffic` from profiles/<round>_hbm_traffic*.json, which must have been
 # measured with these very kernel sources (kernel_source_hash)
-for fl in f32 i8; do
-  flag=""; [ $fl = i8 ] && flag="--int8"
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
+# (LPCNET_HIP_NO_AUTOTUNE=1: only the workload's launches in the traces -- the auto-tune's short trial launches of every streams-per-workgroup
+# variant would be averaged into the kernel statistics; the table value is what the tuned bench line chooses on this model, see `streams_per_workgroup`)
+for fl in f32 i8 f32_fast i8_fast; do
+  case $fl in f32) flag="";; i8) flag="--int8";; f32_fast) flag="--fast";; i8_fast) flag="--int8 --fast --spw 2";; esac
+  if [ $fl = f32 ] || [ $fl = i8 ]; then
+    LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1
+  fi
+  LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
+  LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
 done
 python tools/profile_summarize.py $RND > /dev/null 2>&1
 timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
@@ -26,16 +30,17 @@ timeout 300 python bench.py --fast --fp16-fc --no-cpu-baseline > $OUT/bench_f32_
 timeout 300 python bench.py --int8 --fast --spw 2 --no-cpu-baseline > $OUT/bench_i8_fast.json 2> $OUT/bench_i8_fast.err
 timeout 300 python bench.py --int8 --fast --fp16-fc --spw 2 --no-cpu-baseline > $OUT/bench_i8_fast_f16.json 2> $OUT/bench_i8_fast_f16.err   # BASELINE config 4 as worded
 timeout 600 python bench.py --gpus 2 --share-device --no-cpu-baseline > $OUT/bench_rehearsal_2ranks.json 2> $OUT/bench_rehearsal_2ranks.err
-# the GRU-B form of round 2 (state from LDS + DPP) on this round's kernel, for the A/B line in DESIGN.md
-LPCNET_HIP_NO_SCALAR_GRUB=1 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_f32_lds_state_grub.json 2> /dev/null
+# BASELINE configs 3 / 4 at full shape on the one GPU there is: 8 ranks x 1024 streams (a plumbing rehearsal, not a scaling number)
+timeout 900 python bench.py --gpus 8 --share-device --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_rehearsal_8ranks.json 2> $OUT/bench_rehearsal_8ranks.err
+timeout 900 python bench.py --gpus 8 --share-device --steps 3 --warmup 1 --no-cpu-baseline --int8 > $OUT/bench_rehearsal_8ranks_int8.json 2> $OUT/bench_rehearsal_8ranks_int8.err
 # BASELINE configs 0 -> 1: the reference's own demo on the engine vs its AVX2 builds, one 10-s feature file (wall seconds incl. process start)
 python tools/rtf_demo.py > $OUT/rtf_demo.json 2> $OUT/rtf_demo.err
 python tools/profile_sq.py --tag $RND > $OUT/sq_f32.log 2>&1
+python tools/profile_sq.py --tag $RND --extra=--fast > $OUT/sq_f32_fast.log 2>&1
 python tools/profile_sq.py --int8 --tag $RND > $OUT/sq_i8.log 2>&1
 # in-kernel s_memtime phase tables (profiling build of the library: LPCN_PROF_MASK=0xFFF python -m lpcnet_amd.build --prof)
 if [ -f lpcnet_amd/liblpcnet_hip_prof.so ]; then
   LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1:1 > $OUT/phase_f32.log 2>&1
-  LPCNET_HIP_NO_SCALAR_GRUB=1 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32_lds_state_grub.log 2>&1
   LPCN_FLAVOUR=int8 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1024:2 > $OUT/phase_i8.log 2>&1
   LPCN_FAST=1 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32_fast.log 2>&1
   LPCN_FAST=1 LPCN_FLAVOUR=int8 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:2 > $OUT/phase_i8_fast.log 2>&1

@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--extra", default="")
     a = ap.parse_args()
-    fl = "i8" if a.int8 else "f32"
+    fl = ("i8" if a.int8 else "f32") + ("_fast" if "--fast" in a.extra else "")
     out_dir = os.path.join(ROOT, "gpurun_out", "sq")
     os.makedirs(out_dir, exist_ok=True)
     os.environ["TMPDIR"] = "/tmp"

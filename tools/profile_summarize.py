@@ -4,7 +4,7 @@ import csv, glob, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_hash: ties the PMC numbers to the kernel sources they were measured with)
 
@@ -27,18 +27,36 @@ def counter_avg(dirname, counter):
         out[k] = (sum(full) / len(full), len(full))
     return out
 
-for fl, suffix in (("f32", ""), ("i8", "_int8")):
+for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast"), ("i8_fast", "_int8_fast")):
     b = os.path.join(SRC, f"bench_{fl}.json")
-    if os.path.exists(b) and os.path.getsize(b):
+    if os.path.exists(b) and os.path.getsize(b) and fl in ("f32", "i8"):
         shutil.copy(b, os.path.join(DST, f"{RND}_bench_n1{suffix}.json"))
+    tr = one(f"stats_{fl}/**/*kernel_trace.csv")
     st = one(f"stats_{fl}/**/*kernel_stats.csv")
-    if st:
+    if tr:
+        # per kernel: the workload's launches only -- dispatches within 20 % of the kernel's longest one (a safeguard: the profiled runs set
+        # LPCNET_HIP_NO_AUTOTUNE=1, so no trial launches should be there at all) -- in rocprofv3's own column layout
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr)):
+            dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        rows = []
+        for k, v in dur.items():
+            full = [x for x in v if x >= 0.8 * max(v)]
+            rows.append((k, len(full), sum(full), sum(full) / len(full), min(full), max(full), len(v) - len(full)))
+        tot = sum(r[2] for r in rows) or 1
+        with open(os.path.join(DST, f"{RND}_kernel_stats{suffix}.csv"), "w") as o:
+            o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline" + (" --int8" if fl == "i8" else "")
+                    + " (LPCNET_HIP_NO_AUTOTUNE=1); per kernel the workload's launches only (Dropped = shorter launches left out)\n")
+            o.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","Dropped"\n')
+            for k, n, t, avg, mn, mx, dropped in sorted(rows, key=lambda r: -r[2]):
+                o.write(f'"{k}",{n},{t},{avg:.1f},{100.0 * t / tot:.2f},{mn},{mx},{dropped}\n')
+    elif st:
         shutil.copy(st, os.path.join(DST, f"{RND}_kernel_stats{suffix}.csv"))
     fe, wr = counter_avg(f"fetch_{fl}", "FETCH_SIZE"), counter_avg(f"write_{fl}", "WRITE_SIZE")
     if fe and wr:
         with open(os.path.join(DST, f"{RND}_pmc_hbm_summary{suffix}.csv"), "w") as o:
             o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-                    + (" --int8" if fl == "i8" else "") + ", MI355X\n")
+                    + {"f32": "", "i8": " --int8", "f32_fast": " --fast", "i8_fast": " --int8 --fast --spw 2"}[fl] + ", MI355X\n")
             o.write("# workload per launch: 1024 streams x 25 frames x 160 samples; values are per-dispatch averages in KB as reported\n")
             o.write("kernel,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg\n")
             for k in sorted(fe):
@@ -55,15 +73,16 @@ for fl, suffix in (("f32", ""), ("i8", "_int8")):
 for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_fast.json", "bench_n1_fast.json"),
                  ("bench_i8_fast.json", "bench_n1_int8_fast.json"), ("rtf_demo.json", "demo_single_stream_rtf.json"),
                  ("bench_f32_fast_f16.json", "bench_n1_fast_fp16fc.json"), ("bench_i8_fast_f16.json", "bench_n1_int8_fast_fp16fc.json"),
-                 ("bench_rehearsal_2ranks.json", "bench_rehearsal_2ranks_one_gpu.json"), ("bench_f32_lds_state_grub.json", "bench_n1_lds_state_grub.json")):
+                 ("bench_rehearsal_2ranks.json", "bench_rehearsal_2ranks_one_gpu.json"), ("bench_rehearsal_8ranks.json", "bench_rehearsal_8ranks_one_gpu.json"),
+                 ("bench_rehearsal_8ranks_int8.json", "bench_rehearsal_8ranks_one_gpu_int8.json")):
     b = os.path.join(SRC, src)
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(DST, f"{RND}_{dst}"))
-for fl, suffix in (("f32", ""), ("i8", "_int8")):
+for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast_f32")):
     b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
     if os.path.exists(b):
         shutil.copy(b, os.path.join(DST, f"{RND}_sq_counters{suffix}.csv"))
-ph = [os.path.join(SRC, f) for f in ("phase_f32.log", "phase_f32_lds_state_grub.log", "phase_i8.log", "phase_f32_fast.log", "phase_i8_fast.log") if os.path.exists(os.path.join(SRC, f))]
+ph = [os.path.join(SRC, f) for f in ("phase_f32.log", "phase_i8.log", "phase_f32_fast.log", "phase_i8_fast.log") if os.path.exists(os.path.join(SRC, f))]
 if ph:
     with open(os.path.join(DST, f"{RND}_phase_clocks.txt"), "w") as o:
         o.write("# in-kernel s_memtime phase table (profiling build: LPCN_PROF_MASK=0xFFF python -m lpcnet_amd.build --prof; LPCNET_HIP_LIB=.../liblpcnet_hip_prof.so\n"
