@@ -224,7 +224,20 @@ typedef struct {
     int cache_valid;                  /* `cached` equals the device copy of the stream state */
     lpcn_stream_state cached;
     pthread_mutex_t run_lock;         /* one device round trip at a time per model */
+    /* combining dispatcher of lpcnet_synthesize (see comb_synthesize) */
+    lpcn_batch_dev *gdev;             /* COMB_MAX streams on the slot's engine, created when two callers first meet */
+    pthread_mutex_t q_lock;
+    pthread_cond_t q_cv;
+    struct comb_req *q_head, *q_tail;
+    int q_leader;                     /* a caller is dispatching (on the device or about to) */
 } registry_entry;
+#define COMB_MAX 256
+/* one waiting lpcnet_synthesize call */
+typedef struct comb_req {
+    LPCNetState *st; const float *feat; short *pcm; int N;
+    int done, rc;
+    struct comb_req *next;
+} comb_req;
 #define MAX_MODELS 256
 #define MAX_RESIDENT 16
 static registry_entry g_reg[MAX_MODELS];
@@ -274,6 +287,7 @@ static int registry_materialize(registry_entry *r)
                     (victim < 0 || g_reg[i].last_use < g_reg[victim].last_use)) victim = i;
             if (victim < 0 || pthread_mutex_trylock(&g_reg[victim].run_lock) != 0) break;       /* everything resident is in a call: go over the limit for now */
             registry_entry *v = &g_reg[victim];
+            if (v->gdev) { lpcn_batch_dev_destroy(v->gdev); v->gdev = NULL; }
             lpcn_batch_dev_destroy(v->dev);
             lpcn_engine_destroy(v->engine);
             __atomic_store_n(&v->dev, (lpcn_batch_dev *)NULL, __ATOMIC_SEQ_CST);
@@ -317,11 +331,14 @@ static int registry_bind(const unsigned char *blob, int len)
             }
         if (slot < 0) { set_err("too many distinct models in use at once through lpcnet_load_model"); return -1; }
         registry_entry *v = &g_reg[slot];
+        if (v->gdev) { lpcn_batch_dev_destroy(v->gdev); v->gdev = NULL; }
         if (v->dev) { lpcn_batch_dev_destroy(v->dev); lpcn_engine_destroy(v->engine); }
         free(v->blob);
         const unsigned gen = v->gen + 1;
         pthread_mutex_unlock(&v->run_lock);
         pthread_mutex_destroy(&v->run_lock);
+        pthread_mutex_destroy(&v->q_lock);
+        pthread_cond_destroy(&v->q_cv);
         memset(v, 0, sizeof(*v));
         v->gen = gen;
     }
@@ -333,6 +350,8 @@ static int registry_bind(const unsigned char *blob, int len)
     r->len = len; r->hash = h;
     if (registry_materialize(r) != 0) { free(r->blob); r->blob = NULL; return -1; }
     pthread_mutex_init(&r->run_lock, NULL);
+    pthread_mutex_init(&r->q_lock, NULL);
+    pthread_cond_init(&r->q_cv, NULL);
     r->used = 1;
     r->last_use = ++g_use_clock;
     return HANDLE(slot);
@@ -345,6 +364,7 @@ void lpcnet_hip_shutdown(void)
     for (int i = 0; i < MAX_MODELS; i++)
         if (g_reg[i].used && g_reg[i].dev) {
             pthread_mutex_lock(&g_reg[i].run_lock);
+            if (g_reg[i].gdev) { lpcn_batch_dev_destroy(g_reg[i].gdev); g_reg[i].gdev = NULL; }
             lpcn_batch_dev_destroy(g_reg[i].dev);
             lpcn_engine_destroy(g_reg[i].engine);
             g_reg[i].dev = NULL; g_reg[i].engine = NULL; g_reg[i].cache_valid = 0;
@@ -445,6 +465,38 @@ int lpcnet_hip_decoder_load_model(LPCNetDecState *st, const unsigned char *data,
     if (!st) { set_err("lpcnet_hip_decoder_load_model: bad arguments"); return -1; }
     return lpcnet_load_model(&st->lpcnet_state, data, len);
 }
+
+/* The registry slot this state runs on, PINNED (neither evicted nor recycled until unpinned) but not locked: resolves the
+ * handle / the default model and makes sure the slot has a device side.  Only g_lock is taken. */
+static registry_entry *pin_entry(LPCNetState *st, const char *who)
+{
+    pthread_mutex_lock(&g_lock);
+    int h = (st->magic == LPCN_MAGIC) ? st->model_id : -1;
+    if (h >= 0 && handle_slot(h) < 0) {
+        pthread_mutex_unlock(&g_lock);
+        fprintf(stderr, "%s: the model bound to this state was evicted (more than %d distinct models bound in this process); "
+                        "call lpcnet_load_model again\n", who, MAX_MODELS);
+        abort();
+    }
+    if (h < 0) {
+        h = default_model_locked();
+        if (h >= 0 && st->magic == LPCN_MAGIC) st->model_id = h;
+    }
+    const int id = handle_slot(h);
+    if (id < 0 || registry_materialize(&g_reg[id]) != 0) {
+        pthread_mutex_unlock(&g_lock);
+        fprintf(stderr, "%s: no model bound to this state and no default model (lpcnet_load_model, lpcnet_hip_set_default_model, "
+                        "$LPCNET_HIP_MODEL or ./weights_blob.bin): %s; the HIP engine has no built-in model and no CPU fallback\n",
+                who, tl_err[0] ? tl_err : "none found");
+        abort();
+    }
+    registry_entry *r = &g_reg[id];
+    r->last_use = ++g_use_clock;
+    __atomic_add_fetch(&r->pins, 1, __ATOMIC_SEQ_CST);
+    pthread_mutex_unlock(&g_lock);
+    return r;
+}
+static void unpin_entry(registry_entry *r) { __atomic_sub_fetch(&r->pins, 1, __ATOMIC_SEQ_CST); }
 
 /* The registry slot this state runs on, locked for one device round trip (unlock with release_entry). */
 static registry_entry *acquire_entry(LPCNetState *st, const char *who)
@@ -588,18 +640,80 @@ void lpcnet_synthesize_impl(LPCNetState *st, const float *features, short *outpu
 /* src/lpcnet.c:279-281.  N <= 160 (every caller in the reference): one fused device pass -- frame kernels and sample
  * kernel back to back, one synchronisation; bit-identical to lpcnet_synthesize_impl(..., 0) (tests/test_gpu_parity.py).
  * N > 160: the reference runs the frame network once and then N samples; so does the two-step form. */
+/* One device pass for `k` queued calls of one model (run_lock held by the caller through acquire_entry). */
+static int comb_run(registry_entry *r, comb_req **grp, int k)
+{
+    if (k == 1) {                                            /* nobody to share with: the single-stream fast path (state upload skipped when the device copy is current) */
+        comb_req *q = grp[0];
+        const int fresh = !(r->cache_valid && memcmp(&r->cached, &q->st->s, sizeof(q->st->s)) == 0);
+        r->cache_valid = 0;
+        int rc = lpcn_batch_dev_set_frame_len(r->dev, q->N);
+        if (!rc) rc = lpcn_batch_dev_run_single(r->dev, fresh ? &q->st->s : NULL, q->feat, q->pcm, &q->st->s);
+        if (!rc) { r->cached = q->st->s; r->cache_valid = 1; }
+        return rc;
+    }
+    if (!r->gdev) {
+        int rc = lpcn_batch_dev_create(&r->gdev, r->engine, COMB_MAX, 1);
+        if (rc) return rc;
+    }
+    const lpcn_stream_state *sin[COMB_MAX];
+    lpcn_stream_state *sout[COMB_MAX];
+    const float *ft[COMB_MAX];
+    short *pc[COMB_MAX];
+    for (int i = 0; i < k; i++) { sin[i] = &grp[i]->st->s; sout[i] = &grp[i]->st->s; ft[i] = grp[i]->feat; pc[i] = grp[i]->pcm; }
+    r->cache_valid = 0;                                      /* (the one-stream batch's device copy is not what these states continue from) */
+    return lpcn_batch_dev_run_group(r->gdev, k, grp[0]->N, sin, ft, pc, sout);
+}
+
+/* src/lpcnet.c:279-281.  N <= 160 (every caller in the reference): one fused device pass -- frame kernels and sample
+ * kernel back to back, one synchronisation; bit-identical to lpcnet_synthesize_impl(..., 0) (tests/test_gpu_parity.py).
+ * N > 160: the reference runs the frame network once and then N samples; so does the two-step form.
+ *
+ * Combining dispatcher (round 4).  The reference is re-entrant per state: a server with one thread per stream scales over
+ * its cores.  Here every state of a model shares one device, so concurrent callers are COMBINED instead of serialised: a
+ * call queues itself on its model's slot; if no pass is being dispatched it becomes the leader, takes every queued call
+ * with its own N (up to COMB_MAX), and runs them as ONE multi-stream pass (each caller's POD state up, frame + sample
+ * kernels, states and PCM down); calls that arrive meanwhile queue up and form the next pass, led by one of them -- group
+ * commit, no timer: a lone caller never waits for company, and under load a pass carries as many streams as arrived during
+ * the previous one.  Results are bit-identical to running the calls one by one (streams are independent). */
 void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)
 {
     if (N <= 0) return;
     if (N > LPCN_FRAME_SIZE) { lpcnet_synthesize_impl(st, features, output, N, 0); return; }
-    registry_entry *r = acquire_entry(st, "lpcnet_synthesize");
-    const int fresh = !(r->cache_valid && memcmp(&r->cached, &st->s, sizeof(st->s)) == 0);
-    r->cache_valid = 0;
-    int rc = lpcn_batch_dev_set_frame_len(r->dev, N);
-    if (!rc) rc = lpcn_batch_dev_run_single(r->dev, fresh ? &st->s : NULL, features, output, &st->s);
-    if (!rc) { r->cached = st->s; r->cache_valid = 1; }
-    release_entry(r);
-    if (rc) device_failure("lpcnet_synthesize");
+    /* the slot of this state's model, pinned while the call is queued (a pinned slot is neither evicted nor recycled) */
+    registry_entry *r = pin_entry(st, "lpcnet_synthesize");      /* (g_lock only: a pass in flight on this model must not keep other callers from queueing) */
+    comb_req me = {st, features, output, N, 0, 0, NULL};
+    pthread_mutex_lock(&r->q_lock);
+    if (r->q_tail) r->q_tail->next = &me; else r->q_head = &me;
+    r->q_tail = &me;
+    while (!me.done) {
+        if (r->q_leader) { pthread_cond_wait(&r->q_cv, &r->q_lock); continue; }
+        /* lead one pass: my own call and everything queued with the same N */
+        r->q_leader = 1;
+        comb_req *grp[COMB_MAX];
+        int k = 0;
+        grp[k++] = &me;
+        comb_req **pp = &r->q_head, *last = NULL;
+        while (*pp) {
+            comb_req *q = *pp;
+            if (q == &me || (q->N == N && k < COMB_MAX && q->st != st)) {
+                if (q != &me) grp[k++] = q;
+                *pp = q->next;                               /* unlink */
+            } else { last = q; pp = &q->next; }
+        }
+        r->q_tail = last;
+        pthread_mutex_unlock(&r->q_lock);
+        registry_entry *r2 = acquire_entry(st, "lpcnet_synthesize");      /* run_lock; re-creates the device side if it was released meanwhile */
+        int rc = comb_run(r2, grp, k);
+        release_entry(r2);
+        pthread_mutex_lock(&r->q_lock);
+        for (int i = 0; i < k; i++) { grp[i]->rc = rc; grp[i]->done = 1; }
+        r->q_leader = 0;
+        pthread_cond_broadcast(&r->q_cv);
+    }
+    pthread_mutex_unlock(&r->q_lock);
+    unpin_entry(r);
+    if (me.rc) device_failure("lpcnet_synthesize");
 }
 
 /* ---- decoder ----------------------------------------------------------------------------------- */

@@ -712,6 +712,47 @@ extern "C" int lpcn_batch_dev_run_single(lpcn_batch_dev *b, const lpcn_stream_st
     return 0;
 }
 
+// Combined pass of the legacy per-frame API (api.c: lpcnet_synthesize callers of one model that arrive while a pass is in
+// flight are served together): k <= capacity independent streams, each with its caller's POD state, one frame of features
+// and frame_len samples -- states up, frame kernels + sample kernel, states and PCM down, ONE synchronisation.  The batch
+// was created with the capacity as its stream count; a pass uses its first k slots.
+extern "C" int lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int frame_len, const lpcn_stream_state *const *st_in, const float *const *feat,
+                                        short *const *pcm, lpcn_stream_state *const *st_out)
+{
+    if (k < 1 || frame_len < 1 || frame_len > LPCN_FRAME_SIZE) { snprintf(g_err, sizeof(g_err), "bad group arguments"); return LPCN_E_ARG; }
+    DeviceGuard guard(b->e->device);
+    const int cap = b->n;
+    if (k > cap) { snprintf(g_err, sizeof(g_err), "group of %d exceeds the batch's %d streams", k, cap); return LPCN_E_ARG; }
+    int rc = ensure_staging(b, (size_t)cap * LPCN_NB_FEAT, (size_t)cap * LPCN_FRAME_SIZE);
+    if (rc) return rc;
+    const size_t sz_st = sizeof(lpcn_stream_state), off_feat = sz_st * cap, off_pcm = off_feat + sizeof(float) * LPCN_NB_FEAT * cap;
+    if (!b->h_pin) HIP_TRY(hipHostMalloc(&b->h_pin, off_pcm + sizeof(short) * LPCN_FRAME_SIZE * cap, hipHostMallocDefault));
+    hipStream_t st = b->e->stream;
+    if ((rc = order_begin(b, st))) return rc;
+    unsigned char *pin = (unsigned char *)b->h_pin;
+    for (int i = 0; i < k; ++i) {
+        memcpy(pin + sz_st * i, st_in[i], sz_st);
+        memcpy(pin + off_feat + sizeof(float) * LPCN_NB_FEAT * i, feat[i], sizeof(float) * LPCN_NB_FEAT);
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_state, pin, sz_st * k, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_feat, pin + off_feat, sizeof(float) * LPCN_NB_FEAT * k, hipMemcpyHostToDevice, st));
+    const int keepS = b->S, keep_len = b->frame_len;
+    const bool keepP = b->pack2, keepA = b->S_auto, keepT = b->tuned;
+    b->n = k; b->frame_len = frame_len; b->S = auto_streams_per_wg(b->e, k); b->pack2 = use_pack2(b->e, k, b->S); b->S_auto = false; b->tuned = true;
+    rc = lpcn_batch_dev_run(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, 0, st);
+    b->n = cap; b->frame_len = keep_len; b->S = keepS; b->pack2 = keepP; b->S_auto = keepA; b->tuned = keepT;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(pin, b->d_state, sz_st * k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(pin + off_pcm, b->d_pcm, sizeof(short) * LPCN_FRAME_SIZE * k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->pending = false;
+    for (int i = 0; i < k; ++i) {
+        memcpy(st_out[i], pin + sz_st * i, sz_st);
+        memcpy(pcm[i], pin + off_pcm + sizeof(short) * LPCN_FRAME_SIZE * i, sizeof(short) * (size_t)frame_len);
+    }
+    return 0;
+}
+
 // Codec path: 8-byte packets [stream][packet][8] -> 4 frames each.  Device pointers, work only enqueued.
 extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
 {

@@ -128,6 +128,8 @@ int  lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n_streams, 
 void lpcn_batch_dev_destroy(lpcn_batch_dev *b);
 int  lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count);           /* lpcnet_reset   */
 int  lpcn_batch_dev_get_state(lpcn_batch_dev *b, int stream, lpcn_stream_state *host);
+int  lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int frame_len, const lpcn_stream_state *const *st_in, const float *const *feat,
+                              short *const *pcm, lpcn_stream_state *const *st_out);      /* k independent streams, one frame each, one synchronisation */
 int  lpcn_batch_dev_tune(lpcn_batch_dev *b);              /* measure the streams per workgroup now, on the engine's own stream */
 int  lpcn_batch_dev_set_state(lpcn_batch_dev *b, int stream, const lpcn_stream_state *host);
 int  lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b);
