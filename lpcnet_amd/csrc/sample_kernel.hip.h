@@ -405,7 +405,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // 148 -> 154.5 M samples/s).  A spilled SGPR comes back with one v_readlane.  The PARITY float kernels are the
     // exception: they have no SGPR to spare (the scalar-state GRU-B owns 36), and the ten more spilled ones cost what the
     // loads did (109.5 M without, 108.7 M with) -- they keep the plain member reads.
-    constexpr bool HOIST = I8 || FAST;
+#ifndef LPCN_HOIST_ALL
+#define LPCN_HOIST_ALL 1
+#endif
+    constexpr bool HOIST = I8 || FAST || LPCN_HOIST_ALL;
     int tracing_s = 0;                                       // tests only: workgroup 0 writes the per-sample trace
     if constexpr (HOIST) { tracing_s = __builtin_amdgcn_readfirstlane((Ap->dbg != nullptr && blockIdx.x == 0) ? 1 : 0); LPCN_REMAT_S(tracing_s); }
 // (the non-hoisted forms spell the tests exactly as before: the PARITY float kernels' register allocation is that fragile)
