@@ -309,7 +309,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 {
     using L = Lds<S>;
     using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
-    using HT = typename std::conditional<I8, typename XVec<S>::type, float4>::type;   // one fetched state block
+#ifndef LPCN_I8_MFMA
+#define LPCN_I8_MFMA 1          // PARITY, int8 blobs, S >= 2: an item's block products of all streams from one v_mfma_i32_4x4x4i8 (exact integers, like v_dot4)
+#endif
+    constexpr bool I8M = I8 && !FAST && S >= 2 && LPCN_I8_MFMA;
+    using HT = typename std::conditional<I8, typename std::conditional<I8M, int, typename XVec<S>::type>::type, float4>::type;   // one fetched state block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const sm_pre = (float *)(smem + L::pre);
     float *const sm_inh = (float *)(smem + L::inh);
@@ -381,7 +385,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         for (int j = 0; j < NW; j += 2) {
             const int p0 = ab[base + (size_t)j * 64];
             const int p1 = (j + 1 < NW) ? ab[base + (size_t)(j + 1) * 64] : 0;
-            if constexpr (I8) offp[j >> 1] = (uint32_t)(p0 * 4 * S) | ((uint32_t)(p1 * 4 * S) << 16);
+            // (I8M: lane k of a quad fetches only stream k's dword -- the matrix pipe forms all (stream, row) pairs of the quad)
+            if constexpr (I8M) offp[j >> 1] = (uint32_t)(p0 * 4 * S + (lane & (S - 1)) * 4) | ((uint32_t)(p1 * 4 * S + (lane & (S - 1)) * 4) << 16);
+            else if constexpr (I8) offp[j >> 1] = (uint32_t)(p0 * 4 * S) | ((uint32_t)(p1 * 4 * S) << 16);
             else offp[j >> 1] = (uint32_t)(L::ha_off(p0) + lane_sel) | ((uint32_t)(L::ha_off(p1) + lane_sel) << 16);
         }
         const auto *ar = as_global(Ap->a_row);
@@ -753,6 +759,20 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         int xs;
                         if constexpr (S == 1) xs = xv; else xs = xv[s];
                         acc[s] = __builtin_bit_cast(float, __builtin_amdgcn_sdot4(w[j], xs, __builtin_bit_cast(int, acc[s]), false));
+                    }
+                } else if constexpr (I8M) {
+                    // register k of the result = (stream k's block) . (this lane's row) as an exact int32, for the quad's streams at once
+                    typedef int i4v __attribute__((ext_vector_type(4)));
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const i4v zero = {0, 0, 0, 0};
+                    const i4v d = __builtin_amdgcn_mfma_i32_4x4x4i8(hq[j % (PF + 1)], w[j], zero, 0, 0, 0);
+                    f2 a01 = {acc[0], acc[1]};
+                    a01 = a01 + (f2){(float)d[0], (float)d[1]};
+                    acc[0] = a01[0]; acc[1] = a01[1];
+                    if constexpr (S == 4) {
+                        f2 a23 = {acc[2], acc[3]};
+                        a23 = a23 + (f2){(float)d[2], (float)d[3]};
+                        acc[2] = a23[0]; acc[3] = a23[1];
                     }
                 } else if constexpr (I8) {
                     // one dot4 = the row's block product for one stream, exact in int32 (src/vec.h:329-334)
@@ -1370,6 +1390,20 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         if constexpr (PACK2) {
                             // 128-VGPR variants (two workgroups per CU): the other workgroup hides the LDS latency, a
                             // two-quad pipeline is enough and keeps the kernel out of scratch memory
+#ifndef LPCN_I8_GB_DEPTH
+#define LPCN_I8_GB_DEPTH 2
+#endif
+                            if constexpr (LPCN_I8_GB_DEPTH == 3) {     // reads two quads ahead
+                                i4 w0 = wq[0], x0 = xq4[0], w1 = wq[8], x1 = xq4[1];
+#pragma unroll 3
+                                for (int q = 0; q < 24; ++q) {
+                                    const i4 w2 = wq[(q + 2) * 8], x2 = xq4[q + 2];     // (past the end on the last trips: padded / unused)
+                                    float d[4];
+                                    dot4_cvt_x4(d, w0[0], w0[1], w0[2], w0[3], x0[0], x0[1], x0[2], x0[3]);
+                                    zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3];
+                                    w0 = w1; x0 = x1; w1 = w2; x1 = x2;
+                                }
+                            } else {
                             i4 w0 = wq[0], x0 = xq4[0];
 #pragma unroll 2
                             for (int q = 0; q < 24; ++q) {
@@ -1378,6 +1412,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                                 dot4_cvt_x4(d, w0[0], w0[1], w0[2], w0[3], x0[0], x0[1], x0[2], x0[3]);
                                 zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3];
                                 w0 = w1; x0 = x1;
+                            }
                             }
                         } else {
                         i4 wA[4], xA[4], wB[4], xB[4];
