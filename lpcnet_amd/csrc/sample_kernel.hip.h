@@ -746,7 +746,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             typedef float negz_t __attribute__((ext_vector_type(4)));
             negz_t negz = {-0.f, -0.f, -0.f, -0.f};
             auto load_negz = [&]() { negz = (negz_t){-0.f, -0.f, -0.f, -0.f}; asm volatile("" : "+v"(negz)); };
-            if constexpr (!I8 && !FAST && S == 4 && LPCN_PARITY_MFMA == 2) load_negz();
+            if constexpr (!I8 && !FAST && S >= 2 && LPCN_PARITY_MFMA == 2) load_negz();
             // one item = (this lane's row) x (one 4-wide input block) for all S streams
             auto mac = [&](const int j) {
                 // one item = (this lane's row) x (one 4-wide input block) for all S streams; per output
@@ -809,14 +809,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     acc[0] = av[0]; acc[1] = av[1];
                     if constexpr (S == 4) { acc[2] = av[2]; acc[3] = av[3]; }
                 }
-                if constexpr (!FAST && S == 4 && LPCN_PARITY_MFMA == 2) {
-                    // the products of a column for all four streams from ONE matrix-pipe instruction (C = -0.0: bit for bit the
-                    // separately rounded product), the sums as two v_pk_add_f32 over stream pairs -- each half of a packed add is
+                if constexpr (!FAST && S >= 2 && LPCN_PARITY_MFMA == 2) {
+                    // the products of a column for all streams of the quad from ONE matrix-pipe instruction (C = -0.0: bit for bit the
+                    // separately rounded product), the sums as v_pk_add_f32 over stream pairs -- each half of a packed add is
                     // rounded on its own, so the order of every row's sum is still the reference's: 4 MFMA + 8 packed adds per
-                    // item instead of 16 DPP multiplies + 16 adds
+                    // item instead of 16 DPP multiplies + 16 adds (S = 2: lanes 2, 3 of a quad repeat streams 0, 1; 4 packed adds)
                     typedef float f4 __attribute__((ext_vector_type(4)));
                     typedef float f2 __attribute__((ext_vector_type(2)));
-                    f2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
+                    f2 a01 = {acc[0], acc[1]}, a23 = {0.f, 0.f};
+                    if constexpr (S == 4) a23 = (f2){acc[2], acc[3]};
                     // (the four products of an item are issued back to back into four result tuples: hipcc otherwise re-uses one
                     // tuple and every column waits out the matrix pipe's latency behind s_nop)
                     f4 pv[4];
@@ -826,9 +827,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         a01 = a01 + __builtin_shufflevector(pv[c], pv[c], 0, 1);
-                        a23 = a23 + __builtin_shufflevector(pv[c], pv[c], 2, 3);
+                        if constexpr (S == 4) a23 = a23 + __builtin_shufflevector(pv[c], pv[c], 2, 3);
                     }
-                    acc[0] = a01[0]; acc[1] = a01[1]; acc[2] = a23[0]; acc[3] = a23[1];
+                    acc[0] = a01[0]; acc[1] = a01[1];
+                    if constexpr (S == 4) { acc[2] = a23[0]; acc[3] = a23[1]; }
                 } else if constexpr (!FAST && S >= 2 && LPCN_PARITY_MFMA) {
                     // PARITY: the same instruction as a MULTIPLIER -- with C = -0.0 the fused result is the separately rounded
                     // product bit for bit (x + (-0) = x, also for zeros), one instruction instead of the four DPP multiplies of a
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_REMAT_S(jstar);
             // The early head of slot 0 (see `hl`): one compile-time chain over the last LPCN_EARLY_MAX items, entered at NW - hl.
             auto run_head = [&]() __attribute__((always_inline)) {
-                if constexpr (!I8 && !FAST && S == 4 && LPCN_PARITY_MFMA == 2) load_negz();
+                if constexpr (!I8 && !FAST && S >= 2 && LPCN_PARITY_MFMA == 2) load_negz();
                 {
                     int r = LPCN_ROW(0);
                     LPCN_REMAT_V(r);
