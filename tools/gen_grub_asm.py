@@ -170,8 +170,78 @@ def main_lds(S):
         print('"%s\\n\\t"' % ln)
 
 
+def main_rl(S):
+    """GRU-B input mat-vec with the state operand in SGPRs again -- but filled from LDS, not from L2: ONE ds_read_b128 per 16
+    blocks brings block b0 + L of the wave's stream to lane L (L < 16), and v_readlane_b32 moves the four values of the block
+    about to be used into an SGPR quad, which v_pk_mul_f32 takes as its scalar operand pair.  Per block: 1 LDS read (the lane's
+    weights) instead of 2, + 4 v_readlane issued two blocks ahead in the shadow of the dependent adds.
+    MEASURED AND REJECTED (round 4): bit-exact, 117.6 vs 125.2 M samples/s -- four v_readlane per block cost more issue time on the
+    GRU-B wave than the broadcast LDS read they replace (the kernel does not include this variant; the generator is kept as the record).
+    Registers: weights ring v[WR], state double buffer v[HS], products v[PS], SGPR quads s[36:51]."""
+    stride = 16 * S
+    ha_off = lambda p: p * stride + (p >> 2) * 16
+    R = 4
+    base = 256 - 8 - 4 * R - 8
+    PS = [base, base + 4]
+    WR = [base + 8 + 4 * i for i in range(R)]
+    HS = [base + 8 + 4 * R, base + 8 + 4 * R + 4]         # state of 16 blocks per buffer: lane L = block b0 + L
+    SQ = [36, 40, 44, 48]                                  # SGPR quads (a ring of four: the 32-block loop body must return to quad 0)
+    CNT = 70
+    BPT = 16
+    LA = R - 1
+    lines = []
+    rdw = lambda slot, blk: f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}"
+    rl = lambda q, buf, lane: [f"v_readlane_b32 s{SQ[q] + j}, v{HS[buf] + j}, {lane}" for j in range(4)]
+    prod = lambda pset, slot, q: [f"v_pk_mul_f32 v[{PS[pset]}:{PS[pset] + 1}], s[{SQ[q]}:{SQ[q] + 1}], v[{WR[slot]}:{WR[slot] + 1}]",
+                                  f"v_pk_mul_f32 v[{PS[pset] + 2}:{PS[pset] + 3}], s[{SQ[q] + 2}:{SQ[q] + 3}], v[{WR[slot] + 2}:{WR[slot] + 3}]"]
+    # %[hl] = LDS address of (stream's state, block = lane & 15) ; advanced by 16 blocks per trip
+    lines += [f"s_mov_b32 s{CNT}, {96 // BPT}",
+              f"ds_read_b128 v[{HS[0]}:{HS[0] + 3}], %[hl]",
+              f"ds_read_b128 v[{HS[1]}:{HS[1] + 3}], %[hl] offset:{ha_off(16)}"]
+    for b in range(LA):
+        lines += [rdw(b % R, b)]
+    lines += [f"s_waitcnt lgkmcnt({LA})"]                   # both state buffers are in (LDS returns in order); weights of block 0.. still in flight
+    lines += rl(0, 0, 0) + rl(1, 0, 1)
+    lines += [f"s_waitcnt lgkmcnt({LA - 1})"] + prod(0, 0, 0)
+    lines += [".p2align 4"] + ["s_nop 0"] * PHASE
+    # two trips per loop iteration so that the state double buffer alternates statically
+    lines += ["1:"]
+    for half in range(2):
+        buf = half
+        for k in range(BPT):
+            kk = half * BPT + k                            # block index inside the iteration (0..31)
+            pr = prod((kk + 1) & 1, (kk + 1) % R, (kk + 1) % 4)
+            a = [f"v_add_f32 %[z], %[z], v{PS[kk & 1] + j}" for j in range(4)]
+            nb, nl = (buf, k + 2) if k + 2 < BPT else (1 - buf, k + 2 - BPT)       # the quad two blocks ahead: buffer, lane
+            r2 = rl((kk + 2) % 4, nb, nl)
+            seq = [rdw((kk + LA) % R, kk + LA)]
+            if k == 2:                                     # this buffer's successor: the state of the 16 blocks two trips ahead is fetched
+                pass
+            seq += [f"s_waitcnt lgkmcnt({LA - 1})", a[0], pr[0], r2[0], a[1], pr[1], r2[1], a[2], r2[2], a[3], r2[3]]
+            lines += seq
+            if k == BPT - 1:
+                # the buffer just finished is refilled with the state two trips ahead (its readlanes are all done: the last quad of
+                # this buffer was read two blocks ago)
+                lines += [f"ds_read_b128 v[{HS[buf]}:{HS[buf] + 3}], %[hl] offset:{ha_off(16 * (half + 2))}", "s_waitcnt lgkmcnt(%d)" % LA]
+    lines += [f"v_add_u32 %[wp], {2 * BPT * 128}, %[wp]",
+              f"v_add_u32 %[hl], {ha_off(2 * BPT)}, %[hl]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 2",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py --rl %d -- do not edit" % S)
+    print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hl] LDS byte address of the state block (lane & 15) of the wave's stream (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"s{i}" for i in range(36, 52)] + [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_RL_CLOBBERS")
+    print("#define LPCN_GRUB_RL_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
 if __name__ == "__main__":
-    if "--lds" in sys.argv:
+    if "--rl" in sys.argv:
+        main_rl(int(sys.argv[sys.argv.index("--rl") + 1]))
+    elif "--lds" in sys.argv:
         main_lds(int(sys.argv[sys.argv.index("--lds") + 1]))
     else:
         main()
