@@ -331,6 +331,33 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
             for (int sl = 0; sl < NSLOT; sl++) { wave_of[sl] = newid[w2[sl]]; items[wave_of[sl]] += slot_max[sl]; }
         }
     }
+    {   /* tools (tools/deal_search.py): LPCN_DEAL_FORCE = "w0,w1,...,w17" puts slot i (candidate slots first, both kinds by descending
+         * length) on wave wi -- a dealing found by MEASUREMENT can be compared with the cost model's; LPCN_DEAL_PRINT=1 prints the map */
+        const char *force = getenv("LPCN_DEAL_FORCE");
+        if (force && *force && deal2 && !for_fast) {
+            int wf[NSLOT], n = 0, cnt[LPCN_WAVES] = {0}, sum[LPCN_WAVES] = {0}, ok = 1;
+            for (const char *q = force; *q && n < NSLOT; n++) { wf[n] = atoi(q); while (*q && *q != ',') q++; if (*q) q++; }
+            for (int sl = 0; ok && sl < NSLOT; sl++) {
+                if (n != NSLOT || wf[sl] < 0 || wf[sl] >= LPCN_WAVES) { ok = 0; break; }
+                cnt[wf[sl]]++; sum[wf[sl]] += slot_max[sl];
+                if (cnt[wf[sl]] > LPCN_MAX_SLOTS) ok = 0;
+            }
+            for (int w = 0; ok && w < LPCN_WAVES; w++) {      /* at most one candidate slot per wave (it runs first / carries the head) */
+                int nc = 0;
+                for (int sl = 0; sl < NSLOT; sl++) if (wf[sl] == w && slot_allh[sl]) nc++;
+                if (nc > 1 || sum[w] > 40) ok = 0;
+            }
+            if (ok) for (int sl = 0; sl < NSLOT; sl++) wave_of[sl] = wf[sl];
+            if (ok) { for (int w = 0; w < LPCN_WAVES; w++) items[w] = sum[w]; }
+            else fprintf(stderr, "LPCN_DEAL_FORCE ignored (needs %d waves 0..%d, <= %d slots and one candidate slot per wave, <= 40 items)\n", NSLOT, LPCN_WAVES - 1, LPCN_MAX_SLOTS);
+        }
+        const char *pr = getenv("LPCN_DEAL_PRINT");
+        if (pr && *pr == '1' && !for_fast) {
+            fprintf(stderr, "LPCN_DEAL slots (length:wave%s):", m->is_int8 ? ", int8" : "");
+            for (int sl = 0; sl < NSLOT; sl++) fprintf(stderr, " %s%d:%d", slot_allh[sl] ? "c" : "", slot_max[sl], wave_of[sl]);
+            fprintf(stderr, "\n");
+        }
+    }
     int *load = items;
     int nw = 1;
     for (int w = 0; w < LPCN_WAVES; w++) if (load[w] > nw) nw = load[w];
