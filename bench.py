@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--int8", action="store_true",
                     help="BASELINE.json config 4: int8 (DOT_PROD) GRU-A/GRU-B weights, bit-exact vs the reference's generic int8 build "
                          "(default: float32 weights, the configuration the metric is quoted on)")
+    ap.add_argument("--densities", default="", help="GRU-A block densities 'z,r,h' of the synthetic model (default 0.05,0.05,0.2 = SURVEY.md section 8d); "
+                    "e.g. 0.07,0.07,0.25 loads the 36-items-per-lane kernel, 0.08,0.08,0.3 the 40-item one (NOT the headline workload)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal of the multi-rank path on ONE GPU: every rank uses device 0 and the control plane is gloo "
                          "(RCCL cannot put two ranks on one device); the line it prints is a plumbing check, not a scaling number")
@@ -270,7 +272,10 @@ def main():
     dev = torch.device("cuda", local)
 
     n, F = a.streams, a.frames
-    blob = synth.blob_bytes(synth.make_model(flavour="int8" if a.int8 else "float"))
+    mk = dict(flavour="int8" if a.int8 else "float")
+    if a.densities:
+        mk["densities"] = tuple(float(x) for x in a.densities.split(","))
+    blob = synth.blob_bytes(synth.make_model(**mk))
     batch = api.LPCNetBatch(n, blob, device=local)
     if a.fast:
         batch.set_fast(2 if a.fp16_fc else 1)
@@ -345,6 +350,9 @@ def main():
         achieved_tflops = launch_flop / (ms_sample * 1e-3) / 1e12
         kernel_rate = samples_per_step / (ms_sample * 1e-3)
         op_bytes = LDS_OPERAND_BYTES_PER_SAMPLE_I8 if a.int8 else LDS_OPERAND_BYTES_PER_SAMPLE
+        nb_a = int(api.check_model(blob)[1][1])
+        if nb_a != 1382:                                     # --densities: another GRU-A (SURVEY.md section 8d's formula: 32 weights + 1 index per block)
+            op_bytes += (nb_a - 1382) * ((32 + 4) if a.int8 else (128 + 4))
         op_gbs = kernel_rate * op_bytes / 1e9
         traffic, traffic_src = None, None
         khash = kernel_source_hash()
@@ -377,6 +385,7 @@ def main():
                                    + ", register-resident block-sparse GRU-A, "
                                    + (("FAST arithmetic (FMA / int32 accumulation, not bit-exact)" + (", fp16 dual FC" if a.fp16_fc else "")) if a.fast else "bit-exact (PARITY) arithmetic"),
                        "arithmetic": "fast" if a.fast else "parity",
+                       "gru_a_blocks": nb_a, "gru_a_densities": a.densities or "0.05,0.05,0.2 (benchmark model)",
                        "streams_per_gpu": n, "frames_per_step": F, "streams_per_workgroup": batch.streams_per_workgroup,
                        "sharding": f"{world} x {n} independent streams, no data-path collective"},
             "roofline": {"bound": "lds_operand_bandwidth", "kernel": "lpcn::sample_kernel",
