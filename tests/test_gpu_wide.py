@@ -325,3 +325,27 @@ def test_legacy_api_combines_concurrent_callers(blob_f32, hip_lib):
     speedup = n * t_solo / t_all
     print("legacy API: 1 thread %.1f x real time, %d threads %.1f x in total (%.1f x one thread)" % (T * 0.01 / t_solo, n, n * T * 0.01 / t_all, speedup))
     assert speedup >= 20.0, (t_solo, t_all, speedup)
+
+
+def test_eight_shards_of_1024_streams_in_c(blob_f32, hip_lib):
+    """BASELINE config 3's shape inside ONE process -- lpcnet_batch_create_sharded with 8 shards x 1024 streams (all on
+    the devices the box has; one GPU carries all eight if there is only one): contiguous blocks, a model copy, buffers, stream and
+    host thread per shard, no exchange.  The first and the last stream of every shard are checked against the oracle."""
+    import torch
+    ndev = max(1, torch.cuda.device_count())
+    devices = [k % ndev for k in range(8)]
+    n, T = 8 * 1024, 5
+    base = distinct_feats(64000, 64, T)
+    feats = np.ascontiguousarray(base[np.arange(n) % 64])          # 64 distinct feature files, laid out so that shard borders fall on different ones
+    b = api.LPCNetBatch(n, blob_f32, devices=devices)
+    sh = b.shards
+    assert len(sh) == 8 and all(c == 1024 for _, c, _ in sh) and [f for f, _, _ in sh] == [1024 * k for k in range(8)]
+    got = b.synthesize(feats)
+    pick = sorted({f for f, _, _ in sh} | {f + c - 1 for f, c, _ in sh})
+    want = orc.synthesize_many(blob_f32, feats[pick])
+    assert first_mismatch(got[pick], want) is None
+    # every stream equals the stream with the same feature file (they all started from reset)
+    for s in (1, 1023, 1024, 4097, 8191):
+        assert np.array_equal(got[s], got[s % 64])
+    assert np.count_nonzero(got) > 0.3 * got.size
+    b.close()
