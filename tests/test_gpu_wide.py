@@ -349,3 +349,46 @@ def test_eight_shards_of_1024_streams_in_c(blob_f32, hip_lib):
         assert np.array_equal(got[s], got[s % 64])
     assert np.count_nonzero(got) > 0.3 * got.size
     b.close()
+
+
+def test_legacy_api_dispatcher_mixed_models_and_frame_lengths(hip_lib):
+    """the combining dispatcher under a mixed load: two models (float and int8 blobs: two registry slots, two queues), callers with
+    different N per call (80 / 160 samples: only equal N share a pass), one thread resetting its state half way -- every thread's
+    output must be what the oracle gives for the same call sequence"""
+    import threading
+    blobs = [synth.blob_bytes(synth.make_model(seed=3100)), synth.blob_bytes(synth.make_model(flavour="int8", seed=3101))]
+    oms = [orc.OracleModel(b) for b in blobs]
+    n, T = 24, 24
+    feats = distinct_feats(62000, n, T)
+    plan = [[160 if (i + t) % 3 else 80 for t in range(T)] for i in range(n)]           # N per call
+    want = []
+    for i in range(n):
+        st = oms[i % 2].new_state()
+        outs = []
+        for t in range(T):
+            if i == 5 and t == T // 2:
+                st.L.orc_state_reset(st.p)
+            o = np.zeros(plan[i][t], np.int16)
+            st.L.orc_synthesize(st.p, np.ascontiguousarray(feats[i, t, :20], np.float32), o, plan[i][t], 0)
+            outs.append(o)
+        want.append(np.concatenate(outs))
+    states = [api.LPCNetState(blobs[i % 2]) for i in range(n)]
+    got = [None] * n
+    start = threading.Barrier(n)
+
+    def work(i):
+        start.wait()
+        outs = []
+        for t in range(T):
+            if i == 5 and t == T // 2:
+                states[i].reset()
+            outs.append(states[i].synthesize(feats[i, t], plan[i][t]))
+        got[i] = np.concatenate(outs)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), i
