@@ -1596,13 +1596,59 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 const int node_level = node > 0 ? 31 - __clz(node) : 0;
                 // (tried: the S x 16 GRU-B state values through one LDS read per lane + v_readlane into SGPR operands instead of
                 // S x 4 broadcast ds_read_b128 per wave: P4 2.2 k -> 2.8 k clk, the 64 v_readlane cost more than the reads)
+                // With the ballot's store in the loop body every stream is a basic block of its own, and hipcc runs the streams one after the
+                // other (state reads -> 16 dependent sums -> table lookup -> ballot).  Evaluating them STAGE BY STAGE instead -- S
+                // interleaved chains, S overlapping activations, the masks stored at the end -- was measured in round 4: the phase is bound by
+                // VALU issue of the two waves per SIMD, not by latency, where the sums are separate multiplies and adds (PARITY fp32 124.2
+                // vs 125.6 M, int8 155.7 vs 157.5 M: slower); FAST float, whose sums are fused and half as many instructions, gains
+                // (161.9 vs 158.9 M) and uses the staged form.
+                constexpr bool P4_STAGED = FAST && !I8;
+                float sumv[S], logit[S];
+                if constexpr (P4_STAGED) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sumv[s] = fcb;
+                    if constexpr (FAST) {
+                        if (fc_f16) {
+                            // fp16 dual FC (FAST sub-option): weights and GRU-B state as halves, fp32 accumulation, two MACs per
+                            // v_dot2_f32_f16 -- half the instructions and half the operand bytes of the tree phase
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                            for (int j = 0; j < NB / 2; ++j)
+#pragma unroll
+                                for (int s = 0; s < S; ++s)
+                                    sumv[s] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, fcw[j]), __builtin_bit_cast(h2, ((const uint32_t *)(smem + L::hBh(Ap->nb_b, I8) + s * 32))[j]), sumv[s], false);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                                for (int s = 0; s < S; ++s) sumv[s] = __builtin_fmaf(fcw[j], sm_hB[s * NB + j], sumv[s]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+#pragma unroll
+                            for (int s = 0; s < S; ++s) sumv[s] = sumv[s] + fcw[j] * sm_hB[s * NB + j];           // src/nnet.c:194-199 (per stream: j = 0..15 in order)
+                    }
+#pragma unroll
+                    for (int s = 0; s < S; ++s) logit[s] = fcf * act_tanh<FAST>(sumv[s], sm_tansig);
+                    unsigned long long mk[S];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
+                        const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, logit[s]), 0xB1, 0xf, 0xf, true));
+                        const float lg = logit[s] + vo;                                 // sum1 += sum2
+                        mk[s] = __ballot((sm_thr[s * 8 + node_level] < lg) && chan == 0 && node > 0);
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) sm_mask[s * 8 + wave] = mk[s];
+                    }
+                } else {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     float sum = fcb;
                     if constexpr (FAST) {
                         if (fc_f16) {
-                            // fp16 dual FC (FAST sub-option): weights and GRU-B state as halves, fp32 accumulation, two MACs per
-                            // v_dot2_f32_f16 -- half the instructions and half the operand bytes of the tree phase
                             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                             const uint32_t *hh = (const uint32_t *)(smem + L::hBh(Ap->nb_b, I8) + s * 32);
 #pragma unroll
@@ -1619,10 +1665,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     const float v = fcf * act_tanh<FAST>(sum, sm_tansig);
                     // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
                     const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-                    const float logit = v + vo;                                     // sum1 += sum2
-                    const bool bit = (sm_thr[s * 8 + node_level] < logit) && chan == 0 && node > 0;
+                    const float lg = v + vo;                                        // sum1 += sum2
+                    const bool bit = (sm_thr[s * 8 + node_level] < lg) && chan == 0 && node > 0;
                     const unsigned long long m = __ballot(bit);
                     if (lane == 0) sm_mask[s * 8 + wave] = m;
+                }
                 }
             }
             // wave 0, before it waits at the barrier: the prediction terms of the next sample that do not involve the
