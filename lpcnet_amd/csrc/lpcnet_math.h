@@ -17,7 +17,7 @@
 LPCN_HD float lpcn_tanh(float x, const float *tab)
 {
     const float ax = fabsf(x);
-    int i = (int)floorf(.5f + 25.f * ax);
+    int i = (int)(.5f + 25.f * ax);                // == (int)floor(.5 + 25*ax) of the reference: the argument is >= 0.5, where truncation IS floor (one VALU instruction less)
     i = i > 200 ? 200 : i;                         // i >= 0 always since ax >= 0
     const float dx = ax - .04f * (float)i;
     const float y = tab[i];
