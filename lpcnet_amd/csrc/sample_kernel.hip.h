@@ -1098,11 +1098,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             {
                 constexpr int NI = NA * S;                                     // items
                 constexpr int NQ = (NI + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
+                constexpr bool FULL = NI % LPCN_WG_THREADS == 0;               // (S = 4: every lane has an item in every round -- no range tests, no selects)
                 float z[NQ], rg[NQ], a[NQ], hold[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int i = tid + q * LPCN_WG_THREADS;
-                    const int ic = i < NI ? i : 0;
+                    const int ic = (FULL || i < NI) ? i : 0;
                     z[q] = sm_pre[ic];
                     rg[q] = sm_pre[NI + ic];
                     a[q] = sm_pre[2 * NI + ic];
@@ -1113,7 +1114,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int i = tid + q * LPCN_WG_THREADS;
-                    a[q] = a[q] * rg[q] + sm_inh[i < NI ? i : 0];
+                    a[q] = a[q] * rg[q] + sm_inh[(FULL || i < NI) ? i : 0];
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) a[q] = act_tanh<FAST>(a[q], sm_tansig);
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     const int n = i / S, s = i % S;
                     const float hnew = z[q] * hold[q] + (1.f - z[q]) * a[q];      // src/nnet.c:447
                     const float hv = ((live_mask >> s) & 1) ? hnew : hold[q];
-                    if (i < NI) {
+                    if (FULL || i < NI) {
                         sm_hT[i] = hv;
                         if constexpr (I8) {                  // next sample's activations, quantised once (src/vec.h:311)
                             const unsigned char qv = (unsigned char)quant_s8(hv);
@@ -1637,7 +1638,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
                         const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, logit[s]), 0xB1, 0xf, 0xf, true));
                         const float lg = logit[s] + vo;                                 // sum1 += sum2
-                        mk[s] = __ballot((sm_thr[s * 8 + node_level] < lg) && chan == 0 && node > 0);
+                        mk[s] = __ballot(sm_thr[s * 8 + node_level] < lg) & (wave == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
                     }
                     if (lane == 0) {
 #pragma unroll
@@ -1666,8 +1667,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     // partner channel sits in the neighbouring lane: quad_perm [1,0,3,2]
                     const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
                     const float lg = v + vo;                                        // sum1 += sum2
-                    const bool bit = (sm_thr[s * 8 + node_level] < lg) && chan == 0 && node > 0;
-                    const unsigned long long m = __ballot(bit);
+                    // (the lanes that carry a decision -- channel 0, node > 0 -- are a constant of the wave: the even lanes, without lane 0 on wave 0)
+                    const unsigned long long m = __ballot(sm_thr[s * 8 + node_level] < lg) & (wave == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
                     if (lane == 0) sm_mask[s * 8 + wave] = m;
                 }
                 }
