@@ -38,7 +38,11 @@ static int pick(int nw, int is_int8, int pack2, int grid, int lds, hipStream_t s
 {
 #ifdef LPCN_ONLY_BENCH_VARIANT       // tools: compile only the benchmark model's PARITY float kernel (quick assembly listings)
     if constexpr (FAST) return (int)hipErrorInvalidValue;
+#if LPCN_ONLY_BENCH_VARIANT == 2     // ... the int8 one (32 items per lane, two workgroups per CU; build with -DLPCN_S=2)
+    else return (is_int8 && nw == 32 && pack2) ? launch<32, true, false, (LPCN_S <= 2)>(grid, lds, st, d_args) : (int)hipErrorInvalidValue;
+#else
     else return (!is_int8 && nw == 30) ? launch<30, false, false>(grid, lds, st, d_args) : (int)hipErrorInvalidValue;
+#endif
 #else
     if (is_int8) {
         switch (nw) {
