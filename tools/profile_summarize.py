@@ -77,7 +77,9 @@ for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_
                  ("bench_rehearsal_8ranks_int8.json", "bench_rehearsal_8ranks_one_gpu_int8.json")):
     b = os.path.join(SRC, src)
     if os.path.exists(b) and os.path.getsize(b):
-        shutil.copy(b, os.path.join(DST, f"{RND}_{dst}"))
+        txt = open(b).read()
+        js = [ln for ln in txt.split("\n") if ln.startswith("{") and ln.rstrip().endswith("}")]      # (multi-rank runs: gloo prints its connection chatter to stdout too)
+        open(os.path.join(DST, f"{RND}_{dst}"), "w").write(js[-1] + "\n" if js and not txt.lstrip().startswith("{\n") else txt)
 for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast_f32")):
     b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
     if os.path.exists(b):
