@@ -128,6 +128,9 @@ template <typename T> __device__ __forceinline__ LPCN_GLOBAL T *as_global_rw(T *
 #define LPCN_REMAT_S(x) asm volatile("" : "+s"(x))
 
 // ---- LDS carve-up (bytes), all offsets multiples of 16 ---------------------------------------
+#ifndef LPCN_PROD_BLOCKS
+#define LPCN_PROD_BLOCKS 48
+#endif
 template <int S> struct Lds {
     static constexpr int HA_STRIDE = 16 * S;                       // bytes per 4-neuron block
     static constexpr int hA     = 0;
@@ -159,7 +162,13 @@ template <int S> struct Lds {
     static constexpr int rowtab = boff + 1216;                      // [3][512] i32: the rows a lane owns (-1: none) -- an LDS read where a VGPR would be spilled to scratch
     static constexpr int bw     = rowtab + 3 * LPCN_WG_THREADS * 4; // [nb_b padded][8][4] f32
     static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 28 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
-    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }                          // (bw pad: the GRU-B pipeline reads ahead)
+    // single-stream PARITY float: idle waves hand GRU-B's chain wave the PRODUCTS of the last PROD_BLOCKS blocks through LDS
+    // ([block][48 rows] float4, 768 B per block) -- the chain then costs one read + four adds per block instead of two reads, two
+    // packed multiplies and four adds.  Only S = 1 has the room (50 KB free of the 160 KB).
+    static constexpr int PROD_BLOCKS = LPCN_PROD_BLOCKS, PROD_FIRST = 96 - PROD_BLOCKS;      // (the two assembly loops are generated for this split)
+    static constexpr int prod_sz = S == 1 ? PROD_BLOCKS * RB * 16 : 0;
+    static constexpr int prod(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }
+    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? 0 : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
     static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
     static constexpr int xqT    = hA + 384 * S;                     // [S][96] dwords: the same, stream-major (GRU-B input)
@@ -405,6 +414,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #endif
     const bool gb_lds = LPCN_GRUB_LDS && !I8 && !FAST && b_dense;
     const bool gb_scalar = !LPCN_GRUB_LDS && !I8 && !FAST && b_dense && Ap->hmir != nullptr;
+#ifndef LPCN_GRUB_PROD
+#define LPCN_GRUB_PROD 1        // 1: single stream per workgroup -- waves 1..3 form the products of GRU-B's last 64 blocks for the chain wave
+#endif
+    const bool gb_prod = LPCN_GRUB_PROD && S == 1 && gb_lds;
     // Argument-block members the sample loop needs on its critical path, fetched ONCE and made opaque: left to itself the
     // compiler re-reads them with a scalar load at every use (cheaper than keeping an SGPR, it thinks), and a scalar load in
     // flight forces every LDS wait behind it to lgkmcnt(0) -- right behind a barrier that is a stall for every wave (int8:
@@ -631,7 +644,29 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (v != want) __builtin_amdgcn_s_sleep(1);
         } while (v != want);
     };
-    if (tid0 == 0) { *(int *)(smem + L::flag) = 0; *(int *)(smem + L::flag + 4) = 0; }
+    // products hand-off (gb_prod): the three producer waves bump a second counter once their blocks are written (a wave's LDS
+    // instructions complete in order: the add is behind the stores)
+    int prseq = 0;
+    const uint32_t prod_cnt_addr = flag_addr + 8;
+    auto prod_arrive = [&]() {
+        int one = 1;
+        unsigned long long ex;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %1, %2\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(ex) : "v"(prod_cnt_addr), "v"(one) : "memory");
+    };
+    auto prod_wait = [&]() {
+        int v;
+        const int want = prseq * 3;
+        do {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(prod_cnt_addr) : "memory");
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v != want) __builtin_amdgcn_s_sleep(1);
+        } while (v != want);
+    };
+    if (tid0 == 0) { *(int *)(smem + L::flag) = 0; *(int *)(smem + L::flag + 4) = 0; *(int *)(smem + L::flag + 8) = 0; }
 
 #if LPCN_ENABLE_PROF      // per-phase shader-clock accounting (profiling builds only: it costs VGPRs)
     unsigned long long *const prof = Ap->prof;
@@ -1309,6 +1344,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             float zrh = 0.f, rec = 0.f;
             const int s = gb_split ? wave / GB_W : wave;     // (stream of a gate wave)
             const int r = lane < RB ? lane : RB - 1;
+            if (gb_prod) ++prseq;
             if (gate_wave) {
                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
                 __builtin_amdgcn_s_setprio(3);                 // (priority 1 or none: the same step time, measured)
@@ -1479,6 +1515,16 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         asm volatile(
 #include "grub_lds_loop_s2.inc"
                             : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
+                    } else if (gb_prod) {
+                        // the first blocks as above, then the products of the others that waves 1..3 have formed meanwhile
+                        asm volatile(
+#include "grub_lds_loop_s1_first.inc"
+                            : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS32_CLOBBERS);
+                        prod_wait();
+                        uint32_t pp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::prod(Ap->nb_b, I8) + r * 16);
+                        asm volatile(
+#include "grub_prod_loop.inc"
+                            : [z] "+v"(zrh), [pp] "+v"(pp32) : : LPCN_GRUB_PROD_CLOBBERS);
                     } else {
                         asm volatile(
 #include "grub_lds_loop_s1.inc"
@@ -1552,6 +1598,37 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 LPCN_PROF(8);      // GRU-B input mat-vec
                 __builtin_amdgcn_s_setprio(0);
+            } else if (gb_prod && wave < LPCN_WAVES / 2) {
+                // ---- single stream: waves 1..3 (idle in this phase) multiply weight x state for GRU-B's last PROD_BLOCKS blocks, every third block
+                // each, and leave the products in LDS for the chain wave (same rounding as its own v_pk_mul_f32: one multiply per term)
+                const int g = r >> 3, ri = r & 7;
+                const unsigned char *wrow = smem + L::bw + (sm_bstart[g] * 8 + ri) * 16 + ((0x321100 >> (4 * g)) & 15) * 128;
+                float4 *pout = (float4 *)(smem + L::prod(Ap->nb_b, I8)) + r;
+                // batches of four blocks: all eight reads first (the stores may alias them as far as the compiler knows), two batches in flight
+                constexpr int PB = 4, NBATCH = ((L::PROD_BLOCKS + 2) / 3 + PB - 1) / PB;   // (the tail of the last batch is clamped to block 95)
+                float4 wv[2][PB], hv[2][PB];
+                auto blk = [&](const int k) { const int b = L::PROD_FIRST + wave - 1 + 3 * k; return b < 96 ? b : 95; };      // (a clamped block is written twice with the same value)
+                auto fetch = [&](const int t) {
+#pragma unroll
+                    for (int k = 0; k < PB; ++k) {
+                        const int b = blk(t * PB + k);
+                        wv[t & 1][k] = *(const float4 *)(wrow + b * 128);
+                        hv[t & 1][k] = *(const float4 *)(smem + L::hA + L::ha_off(b));
+                    }
+                };
+                fetch(0);
+#pragma unroll
+                for (int t = 0; t < NBATCH; ++t) {
+                    if (t + 1 < NBATCH) fetch(t + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < PB; ++k) {
+                        const float4 w4 = wv[t & 1][k], h4 = hv[t & 1][k];
+                        pout[(blk(t * PB + k) - L::PROD_FIRST) * RB] = make_float4(h4.x * w4.x, h4.y * w4.y, h4.z * w4.z, h4.w * w4.w);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                prod_arrive();
             } else if (early_wave) {
                 // ---- the head of the next sample's candidate chains (runs in the shadow of GRU-B)
                 run_head();

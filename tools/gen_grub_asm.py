@@ -29,6 +29,8 @@ import sys
 PHASE = int(sys.argv[sys.argv.index("--phase") + 1]) if "--phase" in sys.argv else 0
 MASK48 = "--mask48" in sys.argv
 RING = int(sys.argv[sys.argv.index("--ring") + 1]) if "--ring" in sys.argv else 4
+NBLK = int(sys.argv[sys.argv.index("--blocks") + 1]) if "--blocks" in sys.argv else 96     # --lds: blocks 0..NBLK-1 only (the rest arrives as products, --prod)
+NAME = sys.argv[sys.argv.index("--name") + 1] if "--name" in sys.argv else "LPCN_GRUB_LDS_CLOBBERS"
 
 
 def pk_mul(dst, sreg, vreg):
@@ -130,15 +132,16 @@ def main_lds(S):
     HR = [base + 8 + 4 * R + 4 * i for i in range(R)]      # state ring
     CNT = 70
     BPT = 16 if 96 % R else (R * (16 // R) if 96 % (R * (16 // R)) == 0 else 12)     # blocks per trip: a multiple of the ring size that divides 96
+    if NBLK % BPT and R == 4: BPT = 8
     if BPT % R: BPT = {4: 16, 5: 15, 6: 12, 3: 12, 8: 16}.get(R, 16)
-    assert 96 % BPT == 0 or R == 5
+    assert NBLK % BPT == 0 or R == 5
     LA = R - 1
     lines = []
     rdw = lambda slot, blk: f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}"
     rdh = lambda slot, blk: f"ds_read_b128 v[{HR[slot]}:{HR[slot] + 3}], %[hp] offset:{ha_off(blk)}"
     prod = lambda pset, slot: [f"v_pk_mul_f32 v[{PS[pset]}:{PS[pset] + 1}], v[{HR[slot]}:{HR[slot] + 1}], v[{WR[slot]}:{WR[slot] + 1}]",
                                f"v_pk_mul_f32 v[{PS[pset] + 2}:{PS[pset] + 3}], v[{HR[slot] + 2}:{HR[slot] + 3}], v[{WR[slot] + 2}:{WR[slot] + 3}]"]
-    lines += [f"s_mov_b32 s{CNT}, {96 // BPT}"]
+    lines += [f"s_mov_b32 s{CNT}, {NBLK // BPT}"]
     if MASK48:          # only the 48 row lanes take part: a quarter less LDS return traffic per read
         lines += ["s_mov_b64 s[72:73], exec", "s_bfm_b64 exec, 48, 0"]
     for b in range(LA):
@@ -163,7 +166,7 @@ def main_lds(S):
     print("// generated by tools/gen_grub_asm.py --lds %d -- do not edit" % S)
     print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of the stream's state, block 0 (in/out VGPR)")
     clob = [f"s{CNT}"] + (["s72", "s73"] if MASK48 else []) + [f"v{i}" for i in range(base, 256)]
-    name = "LPCN_GRUB_LDS_CLOBBERS"
+    name = NAME
     print("#undef " + name)
     print("#define " + name + " " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
     for ln in lines:
@@ -238,8 +241,46 @@ def main_rl(S):
         print('"%s\\n\\t"' % ln)
 
 
+def main_prod(nblk):
+    """The tail of the single-stream GRU-B chain with the PRODUCTS ready in LDS: idle waves of the workgroup have multiplied
+    weight x state for blocks 96-nblk..95 (one float4 per row and block, 768 bytes per block: 48 rows) while the chain wave
+    summed the first blocks itself.  Per block: ONE ds_read_b128 and the four dependent v_add_f32 -- the chain at its floor.
+    Ring of 8 blocks in flight (7 x 27 clk of lookahead > the LDS latency)."""
+    R = 8
+    base = 256 - 4 * R
+    RG = [base + 4 * i for i in range(R)]
+    CNT = 70
+    BPT = 16 if nblk % 16 == 0 else 8
+    assert nblk % BPT == 0
+    LA = R - 1
+    rd = lambda slot, blk: f"ds_read_b128 v[{RG[slot]}:{RG[slot] + 3}], %[pp] offset:{blk * 768}"
+    lines = [f"s_mov_b32 s{CNT}, {nblk // BPT}"]
+    for b in range(LA):
+        lines += [rd(b % R, b)]
+    lines += [f"s_waitcnt lgkmcnt({LA - 1})", ".p2align 4", "1:"]
+    for k in range(BPT):
+        a = [f"v_add_f32 %[z], %[z], v{RG[k % R] + j}" for j in range(4)]
+        # the read of the block seven ahead issues in the shadow of the first dependent add; the wait for the NEXT block's
+        # products sits behind the last add (LDS returns in order: at most LA - 1 younger reads may still be out)
+        lines += [a[0], rd((k + LA) % R, k + LA), a[1], a[2], a[3], f"s_waitcnt lgkmcnt({LA - 1})"]          # (reads past the end on the last trip: unused)
+    lines += [f"v_add_u32 %[pp], {BPT * 768}, %[pp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py --prod %d -- do not edit" % nblk)
+    print("// operands: %[z] float accumulator (in/out VGPR), %[pp] LDS byte address of the lane's row in the first product block (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_PROD_CLOBBERS")
+    print("#define LPCN_GRUB_PROD_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
 if __name__ == "__main__":
-    if "--rl" in sys.argv:
+    if "--prod" in sys.argv:
+        main_prod(int(sys.argv[sys.argv.index("--prod") + 1]))
+    elif "--rl" in sys.argv:
         main_rl(int(sys.argv[sys.argv.index("--rl") + 1]))
     elif "--lds" in sys.argv:
         main_lds(int(sys.argv[sys.argv.index("--lds") + 1]))
