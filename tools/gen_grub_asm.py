@@ -277,8 +277,61 @@ def main_prod(nblk):
         print('"%s\\n\\t"' % ln)
 
 
+def main_dpp(S):
+    """GRU-B input mat-vec with ONE state read per FOUR blocks: lane k of a quad (four consecutive rows: same stream, same row
+    group) fetches block 4q + k of the wave's stream, and the four rows take each block's values through quad broadcasts folded
+    into the multiplies (v_mul_f32_dpp quad_perm:[j,j,j,j]).  1.25 LDS instructions per block instead of 2; eight full-rate
+    VALU instructions per block (4 DPP multiplies + 4 dependent adds) instead of 2 packed multiplies + 4 adds -- the same issue
+    time.  Products of block b+1 are formed in the shadow of the adds of block b.
+    %[hp] = LDS address of (stream's state, block = lane & 3); weights as in --lds.
+    MEASURED AND REJECTED (round 4): bit-exact at the first attempt, 123.1 vs 126.7 M samples/s at S = 4, 72.7 vs 75.4 M at
+    512 streams (S = 2) -- the loop is bound by the issue time of the chain wave's own instructions, and four DPP multiplies
+    take more of it than two packed multiplies + the second read (the kernel does not include this variant)."""
+    stride = 16 * S
+    qstep = 4 * stride + 16                        # bytes from one quad of blocks to the next (16 B pad every 4 blocks)
+    base = 256 - 32
+    PS = [base, base + 4]
+    WR = [base + 8 + 4 * i for i in range(4)]
+    HS = [base + 24, base + 28]
+    CNT = 70
+    BPT = 16
+    lines = []
+    rdw = lambda blk: f"ds_read_b128 v[{WR[blk % 4]}:{WR[blk % 4] + 3}], %[wp] offset:{blk * 128}"
+    rdh = lambda q: f"ds_read_b128 v[{HS[q & 1]}:{HS[q & 1] + 3}], %[hp] offset:{q * qstep}"
+    def prod(blk):                                 # products of block `blk` (index inside the trip, may be 16 = next trip's block 0)
+        q, j = blk // 4, blk % 4
+        return [f"v_mul_f32_dpp v{PS[blk & 1] + c}, v{HS[q & 1] + c}, v{WR[blk % 4] + c} quad_perm:[{j},{j},{j},{j}] row_mask:0xf bank_mask:0xf" for c in range(4)]
+    lines += [f"s_mov_b32 s{CNT}, {96 // BPT}", rdh(0), rdw(0), rdw(1), rdw(2), "s_waitcnt lgkmcnt(2)"] + prod(0)
+    lines += [".p2align 4"] + ["s_nop 0"] * PHASE + ["1:"]
+    for k in range(BPT):
+        j = k % 4
+        lines += [rdw(k + 3)]
+        if j == 0:
+            lines += [rdh(k // 4 + 1)]
+        lines += [f"s_waitcnt lgkmcnt({2 if j == 3 else 3})"]
+        a = [f"v_add_f32 %[z], %[z], v{PS[k & 1] + c}" for c in range(4)]
+        m = prod(k + 1)
+        lines += [a[0], m[0], a[1], m[1], a[2], m[2], a[3], m[3]]
+    # (the trip's last products were formed from ring slot (16 % 4) = 0 and state buffer (16 // 4) & 1 = 0: the next trip's block 0)
+    lines += [f"v_add_u32 %[wp], {BPT * 128}, %[wp]",
+              f"v_add_u32 %[hp], {4 * qstep}, %[hp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py --dpp %d -- do not edit" % S)
+    print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of the stream's state, block (lane & 3) (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_DPP_CLOBBERS")
+    print("#define LPCN_GRUB_DPP_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
 if __name__ == "__main__":
-    if "--prod" in sys.argv:
+    if "--dpp" in sys.argv:
+        main_dpp(int(sys.argv[sys.argv.index("--dpp") + 1]))
+    elif "--prod" in sys.argv:
         main_prod(int(sys.argv[sys.argv.index("--prod") + 1]))
     elif "--rl" in sys.argv:
         main_rl(int(sys.argv[sys.argv.index("--rl") + 1]))
