@@ -73,3 +73,23 @@ def test_nothing_in_the_sample_loop_forces_full_lds_waits(rows):
     assert rows[(30, False, False)]["sgpr_reloads_in_sample_loop"] <= 40, rows[(30, False, False)]
     for key in [(32, True, False), (32, True, True), (30, False, True)]:
         assert rows[key]["sgpr_reloads_in_sample_loop"] <= 10, (key, rows[key])
+
+
+def test_generated_assembly_loops_are_what_the_generator_emits():
+    """GRU-B's hand-scheduled loops are generated (tools/gen_grub_asm.py) and committed; the single-stream pair -- the chain
+    wave's first blocks, then the products its helper waves leave in LDS -- must be generated for the split the kernel is
+    compiled with (LPCN_PROD_BLOCKS), or blocks would be summed twice or not at all."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "lpcnet_amd", "csrc")
+    gen = os.path.join(ROOT, "tools", "gen_grub_asm.py")
+    m = re.search(r"#define LPCN_PROD_BLOCKS (\d+)", open(os.path.join(csrc, "sample_kernel.hip.h")).read())
+    prod = int(m.group(1))
+    assert 0 < prod < 96 and prod % 8 == 0 and (96 - prod) % 8 == 0
+    assert prod * 48 * 16 + 113392 <= 160 * 1024            # the products + the rest of the single-stream carve-up fit the CU's LDS
+    cases = [(["--lds", "1"], "grub_lds_loop_s1.inc"), (["--lds", "2"], "grub_lds_loop_s2.inc"), (["--lds", "4"], "grub_lds_loop_s4.inc"),
+             (["--lds", "1", "--blocks", str(96 - prod), "--name", "LPCN_GRUB_LDS32_CLOBBERS"], "grub_lds_loop_s1_first.inc"),
+             (["--prod", str(prod)], "grub_prod_loop.inc"), ([], "grub_scalar_loop.inc")]
+    for args, name in cases:
+        out = subprocess.run([sys.executable, gen] + args, capture_output=True, text=True, check=True).stdout
+        assert out == open(os.path.join(csrc, name)).read(), name
