@@ -328,8 +328,62 @@ def main_dpp(S):
         print('"%s\\n\\t"' % ln)
 
 
+def main_i8(base):
+    """GRU-B input mat-vec of the int8 PARITY kernels, dense input matrix: per block one exact v_dot4_i32_i8 (4 int8 weights x 4
+    quantised state values), converted to float and added to the running sum in block order (src/vec.h:306-339).  One 16-byte
+    read brings the lane's weights of FOUR blocks, another the stream's quantised state of the same four: a "quad".  Ring of
+    --ring R quads (R - 1 in flight), the dots and conversions of quad q+1 in the shadow of the four dependent adds of quad q.
+    The compiler's version of this loop waits for each pair of reads right behind their issue (~150 clk exposed per quad).
+    gfx90a+ hazard: 3 wait states between a DOT write and another VALU reading it -- the four conversions follow the four dots,
+    with the adds in between.   `base` = first clobbered VGPR (a 128-VGPR kernel needs them below v128).
+    MEASURED AND NOT KEPT (round 4): bit-exact; GRU-B 3.9 k -> 2.8 k clk per step in the phase table of the int8 kernel with two
+    workgroups per CU, throughput unchanged (158.0 vs 158.7 M samples/s; 137.0 vs 137.1 M at S = 4): the second workgroup
+    fills the wait either way."""
+    R = RING
+    WR = [base + 4 * i for i in range(R)]
+    XR = [base + 4 * R + 4 * i for i in range(R)]
+    D = base + 8 * R
+    F = base + 8 * R + 4
+    top = base + 8 * R + 8
+    CNT = 70
+    NQ = 24
+    assert NQ % R == 0
+    LA = R - 1
+    rdw = lambda q: f"ds_read_b128 v[{WR[q % R]}:{WR[q % R] + 3}], %[wp] offset:{q * 128}"
+    rdx = lambda q: f"ds_read_b128 v[{XR[q % R]}:{XR[q % R] + 3}], %[xp] offset:{q * 16}"
+    dots = lambda q: [f"v_dot4_i32_i8 v{D + k}, v{WR[q % R] + k}, v{XR[q % R] + k}, 0" for k in range(4)]
+    cvts = [f"v_cvt_f32_i32 v{F + k}, v{D + k}" for k in range(4)]
+    lines = [f"s_mov_b32 s{CNT}, {NQ // R}"]
+    for q in range(LA):
+        lines += [rdw(q), rdx(q)]
+    lines += [f"s_waitcnt lgkmcnt({2 * (LA - 1)})"] + dots(0) + cvts
+    lines += [".p2align 4", "1:"]
+    for q in range(R):
+        a = [f"v_add_f32 %[z], %[z], v{F + k}" for k in range(4)]
+        d = dots(q + 1)
+        # (the conversions of quad q+1 overwrite the four floats of quad q behind its last add)
+        lines += [rdw(q + LA), rdx(q + LA), f"s_waitcnt lgkmcnt({2 * (LA - 1)})",
+                  a[0], d[0], a[1], d[1], a[2], d[2], a[3], d[3]] + cvts
+    lines += [f"v_add_u32 %[wp], {R * 128}, %[wp]",
+              f"v_add_u32 %[xp], {R * 16}, %[xp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py --i8 %d --ring %d -- do not edit" % (base, R))
+    print("// operands: %[z] float accumulator (in/out VGPR), %[wp] LDS byte address of the lane's row, quad 0 (in/out VGPR), %[xp] LDS byte address of the stream's quantised state (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"v{i}" for i in range(base, top)]
+    name = "LPCN_GRUB_I8_CLOBBERS_%d" % base
+    print("#undef " + name)
+    print("#define " + name + " " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
 if __name__ == "__main__":
-    if "--dpp" in sys.argv:
+    if "--i8" in sys.argv:
+        main_i8(int(sys.argv[sys.argv.index("--i8") + 1]))
+    elif "--dpp" in sys.argv:
         main_dpp(int(sys.argv[sys.argv.index("--dpp") + 1]))
     elif "--prod" in sys.argv:
         main_prod(int(sys.argv[sys.argv.index("--prod") + 1]))
