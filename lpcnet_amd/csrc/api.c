@@ -637,9 +637,6 @@ void lpcnet_synthesize_impl(LPCNetState *st, const float *features, short *outpu
     lpcnet_synthesize_tail_impl(st, output, N, preload);
 }
 
-/* src/lpcnet.c:279-281.  N <= 160 (every caller in the reference): one fused device pass -- frame kernels and sample
- * kernel back to back, one synchronisation; bit-identical to lpcnet_synthesize_impl(..., 0) (tests/test_gpu_parity.py).
- * N > 160: the reference runs the frame network once and then N samples; so does the two-step form. */
 /* One device pass for `k` queued calls of one model (run_lock held by the caller through acquire_entry). */
 static int comb_run(registry_entry *r, comb_req **grp, int k)
 {
