@@ -198,15 +198,115 @@ def cpu_baseline(int8_line=False):
 
 
 def kernel_source_hash():
-    """sha1 over the device sources: ties a PMC traffic file under profiles/ to the kernel it was measured with"""
-    import hashlib
-    h = hashlib.sha1()
-    d = os.path.join(ROOT, "lpcnet_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".inc", ".c")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """sha1 over the DEVICE sources (*.hip, *.hip.h, *.inc, the headers they include, the device compile flags): ties a PMC
+    traffic file under profiles/ to the kernels it was measured with.  Host-only changes (api.c, model_pack.c) do not move it
+    (a comment-only commit to api.c orphaned the round's HBM figures)."""
+    from lpcnet_amd import build
+    return build.source_hashes()[1]
+
+
+FRAME_DEADLINE_MS = 10.0                # one frame = 160 samples at 16 kHz
+
+
+def rt_main(a, world, rank, local, dev):
+    """Real-time operating point: n streams advance ONE frame per step, like the reference's callers do
+    (src/lpcnet_demo.c:203-219: one lpcnet_synthesize per 10-ms frame); the step is enqueued on the device-pointer API
+    (frame kernels + sample kernel) and waited for, and its wall time -- host clock around enqueue + synchronise, i.e. what a
+    server thread sees -- must stay under the 10-ms frame period for the batch to keep up with real time."""
+    import torch
+    import torch.distributed as dist
+    from lpcnet_amd import api, synth
+    counts = [int(x) for x in a.rt_sweep.split(",") if x] or [a.streams]
+    steps, warm = max(a.steps, 1), max(a.warmup, 3)
+    blob = synth.blob_bytes(synth.make_model(flavour="int8" if a.int8 else "float"))
+    stream = torch.cuda.current_stream().cuda_stream
+    results = []
+    for n in counts:
+        batch = api.LPCNetBatch(n, blob, device=local)
+        if a.fast:
+            batch.set_fast(2 if a.fp16_fc else 1)
+        if a.spw:
+            batch.streams_per_workgroup = a.spw
+        else:
+            batch.tune()
+        T = warm + steps
+        k = 0 if a.fast else min(a.check_streams, n)
+        pick = sorted({(i * n) // k + (i % 4 if n >= 4 * k else 0) for i in range(k)}) if k else []
+        # every stream its own feature sequence; laid out [frame][stream][36] so that one step's features are contiguous.
+        # (distinct files for the streams that are checked, and a pool of 64 files cycled over the rest: generating 8192 x 500-frame files
+        # on the host would take longer than the measurement)
+        pool = np.stack([synth.make_features(5000 + rank * 64 + i, T) for i in range(64)])
+        d_feat = torch.from_numpy(pool).to(dev)[torch.arange(n, device=dev) % 64].permute(1, 0, 2).contiguous()      # [T][n][36]
+        picked = {sidx: synth.make_features(9000 + rank * n + sidx, T) for sidx in pick}
+        for sidx, f in picked.items():
+            d_feat[:, sidx] = torch.from_numpy(f).to(dev)
+        d_pcm = torch.zeros((T, n, 160), dtype=torch.int16, device=dev)
+        if world > 1:
+            dist.barrier()
+        lat = np.zeros(T)
+        for t in range(T):
+            t0 = time.perf_counter()
+            batch.synthesize_device(d_feat[t].data_ptr(), 36, d_pcm[t].data_ptr(), 1, stream)
+            torch.cuda.synchronize()
+            lat[t] = (time.perf_counter() - t0) * 1e3
+        timed = lat[warm:]
+        # device-side time of a step alone (HIP events on the kernels' stream), a few steps past the end
+        batch.enable_timing(True)
+        ks = []
+        for _ in range(3):
+            batch.synthesize_device(d_feat[T - 1].data_ptr(), 36, d_pcm[T - 1].data_ptr(), 1, stream)
+            torch.cuda.synchronize()
+            ks.append(batch.last_timing())
+        batch.enable_timing(False)
+        parity = 0
+        if rank == 0 and pick:
+            from oracle import orc
+            want = orc.synthesize_many(blob, np.stack([picked[sidx] for sidx in pick]))      # [k][T*160] from reset
+            got = d_pcm[:, pick].cpu().numpy().transpose(1, 0, 2).reshape(len(pick), T * 160)
+            if not np.array_equal(got, want):
+                raise SystemExit(f"bench.py --rt: output of the timed steps differs from the CPU oracle ({n} streams)")
+            parity = len(pick)
+        p50, p99, mx = float(np.percentile(timed, 50)), float(np.percentile(timed, 99)), float(timed.max())
+        results.append({"streams": n, "steps": steps, "step_ms_p50": p50, "step_ms_p99": p99, "step_ms_max": mx, "step_ms_mean": float(timed.mean()),
+                        "deadline_ms": FRAME_DEADLINE_MS, "meets_deadline_p99": bool(p99 < FRAME_DEADLINE_MS),
+                        "over_deadline_steps": int((timed >= FRAME_DEADLINE_MS).sum()),
+                        "realtime_factor_p99": FRAME_DEADLINE_MS / p99,
+                        "samples_per_s_at_p50": n * 160 / (p50 * 1e-3),
+                        "kernel_ms": {"sample": float(np.median([x[0] for x in ks])), "frame": float(np.median([x[1] for x in ks]))},
+                        "streams_per_workgroup": batch.streams_per_workgroup, "parity_checked": parity})
+        batch.close()
+        del d_feat, d_pcm
+    if world > 1:
+        for r in results:                                    # every rank must hold the deadline: the worst rank's figures
+            t = torch.tensor([r["step_ms_p50"], r["step_ms_p99"], r["step_ms_max"]], dtype=torch.float64, device="cpu" if a.share_device else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r["step_ms_p50"], r["step_ms_p99"], r["step_ms_max"] = (float(x) for x in t.tolist())
+            r["meets_deadline_p99"] = bool(r["step_ms_p99"] < FRAME_DEADLINE_MS)
+        dist.barrier()
+    if rank == 0:
+        ok = [r for r in results if r["meets_deadline_p99"]]
+        best = max(ok, key=lambda r: r["streams"]) if ok else None
+        head = best or min(results, key=lambda r: r["streams"])
+        from lpcnet_amd import api as _api
+        out = {"metric": "16 kHz samples/sec & concurrent real-time streams, 1/2/4/8 MI355X",
+               "value": world * head["streams"] * 160 / (head["step_ms_p50"] * 1e-3), "unit": "samples/s",
+               "realtime_streams_sustained": world * best["streams"] if best else 0,
+               "realtime_streams_sustained_note": "largest measured stream count per GPU whose p99 step time (one 10-ms frame for every stream, enqueue + wait) "
+                                                  "stays under the 10-ms frame period, x GPUs; 0 = none of the measured counts does",
+               "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": head["step_ms_mean"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int8 weights/activations x f32 accumulate (GRU-A/GRU-B), f32 elsewhere" if a.int8 else "f32", "data": "synthetic",
+               "parity_checked": head["parity_checked"],
+               "config": {"workload": f"REAL-TIME operating point: {head['streams']} concurrent streams per GPU, ONE 10-ms frame per step and stream "
+                                      "(frame network + LPC + 160 samples), each step enqueued and waited for; "
+                                      + ("int8 GRU weights" if a.int8 else "fp32 weights") + ", " + ("FAST arithmetic" if a.fast else "bit-exact (PARITY) arithmetic"),
+                          "arithmetic": "fast" if a.fast else "parity", "frames_per_step": 1, "streams_per_gpu": head["streams"],
+                          "sharding": f"{world} x n independent streams, no data-path collective"},
+               "rt": results, "library_build_info": _api.build_info(), "kernel_source_hash": kernel_source_hash(),
+               "library_matches_sources": _api.build_info().get("dev") == kernel_source_hash()}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def _self_launch(a):
@@ -244,6 +344,13 @@ def main():
                          "(default: float32 weights, the configuration the metric is quoted on)")
     ap.add_argument("--densities", default="", help="GRU-A block densities 'z,r,h' of the synthetic model (default 0.05,0.05,0.2 = SURVEY.md section 8d); "
                     "e.g. 0.07,0.07,0.25 loads the 36-items-per-lane kernel, 0.08,0.08,0.3 the 40-item one (NOT the headline workload)")
+    ap.add_argument("--rt", action="store_true",
+                    help="the operating point the metric is NAMED after: frame-at-a-time synthesis (one lpcnet_synthesize per 10-ms frame and "
+                         "stream, src/lpcnet_demo.c:203-219) of --streams concurrent streams against the 10-ms frame deadline -- every step is one "
+                         "frame for every stream (frame network + LPC + 160 samples), enqueued and WAITED for; reports the per-step wall time "
+                         "(p50 / p99 / max over --steps steps) and whether the batch keeps up with real time (p99 < 10 ms)")
+    ap.add_argument("--rt-sweep", default="", help="with --rt: comma-separated stream counts to measure in one run (the line carries all of them; "
+                    "`value` is the rate at the largest count whose p99 meets the deadline)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal of the multi-rank path on ONE GPU: every rank uses device 0 and the control plane is gloo "
                          "(RCCL cannot put two ranks on one device); the line it prints is a plumbing check, not a scaling number")
@@ -271,6 +378,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if a.rt:
+        return rt_main(a, world, rank, local, dev)
     n, F = a.streams, a.frames
     mk = dict(flavour="int8" if a.int8 else "float")
     if a.densities:
@@ -356,7 +465,7 @@ def main():
         op_gbs = kernel_rate * op_bytes / 1e9
         traffic, traffic_src = None, None
         khash = kernel_source_hash()
-        for rnd in ("r04", "r03", "r02", "r01"):             # PMC passes of this command, newest round first
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):      # PMC passes of this command, newest round first
             tag = ("_int8" if a.int8 else "") + ("_fast" if a.fast else "")
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic{tag}.json")
             if os.path.exists(tpath) and (n, F) == (STREAMS_PER_GPU, FRAMES_PER_STEP):
@@ -397,7 +506,8 @@ def main():
                                  "GRU-A weights in VGPRs and shares every LDS read among the workgroup's streams, so realised LDS bytes are lower; "
                                  "`traffic` comes from the rocprofv3 PMC passes recorded under profiles/ (it cannot be collected from inside the "
                                  "process) and is null unless that file was measured with these very kernel sources",
-                         "kernel_source_hash": khash,
+                         "kernel_source_hash": khash, "library_build_info": api.build_info(),
+                         "library_matches_sources": api.build_info().get("dev") == khash,
                          "valu_fp32": {"achieved_TFLOPs": achieved_tflops, "peak_TFLOPs": PEAK_FP32_TFLOPS,
                                        "frac": achieved_tflops / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE,
                                        "measured_packed_mul_add_no_fma_TFLOPs": MEASURED_FP32_MUL_ADD_TFLOPS,

@@ -19,8 +19,13 @@
  *     approximations): float ("DISABLE_DOT_PROD") blobs like its generic float build, int8
  *     ("DOT_PROD") blobs like its generic int8 build; the flavour is detected from the blob.
  *   - All compute runs on a HIP device; there is no CPU fallback.  If no device is usable,
- *     lpcnet_load_model() returns -1 and lpcnet_hip_last_error() says why; entry points that return
- *     void in the reference abort with a message on an unrecoverable device error.
+ *     lpcnet_load_model() returns -1 and lpcnet_hip_last_error() says why.  Entry points that return
+ *     void in the reference (lpcnet_synthesize, run_frame_network, lpcnet_synthesize_impl/_tail_impl)
+ *     never abort: a call that fails -- device error, no model and no default model, evicted model --
+ *     zero-fills its output (silence / zero frame products), leaves the caller's state untouched and
+ *     records the failure in a sticky per-thread status (lpcnet_hip_status(), lpcnet_hip_last_error())
+ *     and a sticky per-model status (lpcnet_hip_model_status()); lpcnet_decode returns -1.
+ *     LPCNET_HIP_ABORT_ON_ERROR=1 in the environment turns such a failure into abort() with the message.
  */
 #ifndef LPCNET_H_
 #define LPCNET_H_
@@ -88,6 +93,21 @@ LPCNET_EXPORT void lpcnet_synthesize_impl(LPCNetState *lpcnet, const float *feat
 /* ---- additions (not in the reference) ------------------------------------------------------ */
 /* message of the last failure on the calling thread ("" if none) */
 LPCNET_EXPORT const char *lpcnet_hip_last_error(void);
+/* Sticky status of the calling thread: 0, or the code of the FIRST void entry point that failed on this thread since
+ * lpcnet_hip_clear_error() (the call zero-filled its output; see the header comment).  Codes: */
+#define LPCNET_HIP_E_NODEVICE (-2)          /* no usable HIP device */
+#define LPCNET_HIP_E_DEVICE   (-3)          /* a HIP call or kernel launch failed */
+#define LPCNET_HIP_E_ARG      (-4)          /* bad argument (e.g. preload outside 0..N) */
+#define LPCNET_HIP_E_MODEL    (-5)          /* no model bound / no default model / model evicted / malformed blob */
+LPCNET_EXPORT int lpcnet_hip_status(void);
+LPCNET_EXPORT void lpcnet_hip_clear_error(void);
+/* Sticky status of the MODEL a state is bound to: 0, or the code of the first failed pass on that model since it was last
+ * cleared (clear != 0 resets it).  A server thread that shares a model with others learns here that some caller's pass
+ * failed -- under the combining dispatcher one failed pass fails every call it carried. */
+LPCNET_EXPORT int lpcnet_hip_model_status(const LPCNetState *st, int clear);
+/* "src=<hash> dev=<hash>": sha1 prefixes of the sources this library was built from (all of lpcnet_amd/csrc + include, and
+ * the device sources alone); bench.py echoes them so that a measurement can be tied to the tree it claims */
+LPCNET_EXPORT const char *lpcnet_hip_build_info(void);
 /* install the VQ codebooks used by lpcnet_decode (the reference compiles them in from
  * ceps_codebooks.c, a generated file that is not part of its tree): cb1..3 [1024][17], diff4 [4096][18] */
 LPCNET_EXPORT void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *cb3, const float *cb_diff4);

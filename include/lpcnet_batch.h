@@ -90,9 +90,11 @@ LPCNET_EXPORT int lpcnet_batch_set_end2end(LPCNetBatch *b, int on);
  * not bit-identical to any reference build (those differ among themselves as well); tests/test_gpu_fast.py keeps its
  * teacher-forced deviation inside the reference's own AVX2-vs-generic envelope.
  * 2 = FAST with the dual fully-connected layer of the sampler in fp16 (weights and GRU-B state as halves, fp32 accumulation,
- * v_dot2_f32_f16): BASELINE.json config 4's "fp16 dual-FC".  The reference has no fp16 arithmetic to pin it to, so it is
- * validated against FAST itself: the share of samples whose tree decision changes under teacher forcing
- * (tests/test_gpu_fast.py::test_fp16_dual_fc_decision_flips). */
+ * v_dot2_f32_f16): BASELINE.json config 4's "fp16 dual-FC".  The reference has no fp16 arithmetic, so the pin is to a stated
+ * definition: the oracle restates it (oracle/lpcnet_oracle.c: orc_mdense_f16_path -- binary16 weights and GRU-B state, fp32
+ * sums, both v_dot2 rounding orders) and replays every tree decision of the engine from the traced GRU-B state against the
+ * reference RNG's thresholds, within a 2e-4 x max(1, |logit|) band (tests/test_gpu_fast.py::
+ * test_fp16_dual_fc_against_the_oracle_restatement; fewer than 1 % of the decisions may fall inside the band). */
 LPCNET_EXPORT int lpcnet_batch_set_fast(LPCNetBatch *b, int on);
 LPCNET_EXPORT int lpcnet_batch_decode_device(LPCNetBatch *b, const unsigned char *d_packets, short *d_pcm, int n_packets,
                                              void *hip_stream);
@@ -124,6 +126,14 @@ LPCNET_EXPORT int lpcnet_batch_run_frames(LPCNetBatch *b, const float *features,
 LPCNET_EXPORT int lpcnet_hip_model_layout(const unsigned char *data, int len, int *out);
 /* the engine's own correctly rounded 10^x of the LPC path (pow(10.f, x) of src/freq.c:317) evaluated on the device */
 LPCNET_EXPORT int lpcnet_hip_exp10_device(const float *x, double *out, int n);
+/* The arithmetic identities the bit-exact (PARITY) kernels rest on, evaluated on the device with the library's own compile flags
+ * and float mode, as bit patterns: v_mfma_f32_4x4x1(A, B, C = -0.0) == v_mul_f32 (out_mfma / out_mul, [n][4]: product k of lane i =
+ * a[4*(i/4) + k] * b[i]) and the halves of v_pk_mul_f32 / v_pk_add_f32 == v_mul_f32 / v_add_f32 (out_pk / out_sc, [n][4] =
+ * {mul (a[i], b[i]), mul (a[i^1], b[i^1]), add (a[i], b[i]), add (a[i^1], b[i^1])}).  n a multiple of 64.
+ * tests/test_gpu_parity.py::test_matrix_pipe_multiplier_and_packed_math_are_exact feeds it stratified operands (subnormal
+ * inputs and products, underflow, +-0, the largest finite products, infinities). */
+LPCNET_EXPORT int lpcnet_hip_arith_identities_device(const float *a, const float *b, unsigned *out_mfma, unsigned *out_mul,
+                                                     unsigned *out_pk, unsigned *out_sc, int n);
 /* raw per-stream state record (layout = struct lpcn_stream_state in lpcnet_amd/csrc/lpcnet_engine.h) */
 LPCNET_EXPORT int lpcnet_batch_state_size(void);
 LPCNET_EXPORT int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out);

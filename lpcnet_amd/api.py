@@ -113,6 +113,12 @@ def load_library():
     L.lpcnet_batch_set_raw_state.argtypes = [vp, C.c_int, vp]
     L.lpcnet_batch_debug_trace.argtypes = [vp, C.c_int, vp]
     L.lpcnet_batch_profile.argtypes = [vp, vp]
+    _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    L.lpcnet_hip_arith_identities_device.argtypes = [_f32p, _f32p, _u32p, _u32p, _u32p, _u32p, C.c_int]
+    L.lpcnet_hip_status.restype = C.c_int
+    L.lpcnet_hip_clear_error.restype = None
+    L.lpcnet_hip_model_status.argtypes = [vp, C.c_int]
+    L.lpcnet_hip_build_info.restype = C.c_char_p
     _lib = L
     return L
 
@@ -126,6 +132,32 @@ def check_model(blob: bytes):
 
 def last_error() -> str:
     return load_library().lpcnet_hip_last_error().decode()
+
+
+def status() -> int:
+    """Sticky per-thread status of the void entry points (0 = no failure since clear_error())."""
+    return load_library().lpcnet_hip_status()
+
+
+def clear_error() -> None:
+    load_library().lpcnet_hip_clear_error()
+
+
+def build_info() -> dict:
+    """{'src': hash of every source the library was built from, 'dev': hash of the device sources alone}"""
+    txt = load_library().lpcnet_hip_build_info().decode()
+    return dict(kv.split("=", 1) for kv in txt.split())
+
+
+def arith_identities(a: np.ndarray, b: np.ndarray):
+    """Bit patterns of (mfma products, v_mul products, packed mul/add halves, scalar mul/add) for operand arrays a, b (float32, len % 64 == 0)."""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    n = a.size
+    outs = [np.empty((n, 4), np.uint32) for _ in range(4)]
+    rc = load_library().lpcnet_hip_arith_identities_device(a, b, *outs, n)
+    if rc:
+        raise LPCNetError(f"lpcnet_hip_arith_identities_device failed ({rc}): " + last_error())
+    return outs
 
 
 class StreamState(C.Structure):

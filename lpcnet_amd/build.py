@@ -24,20 +24,55 @@ C_FLAGS = ["-O2", "-fPIC", "-ffp-contract=off", "-std=gnu11", "-Wall", "-fvisibi
            "-I" + CSRC, "-I" + os.path.join(HERE, "..", "include")]
 
 
-def _newer(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def source_hashes(extra_flags=()):
+    """(src, dev): sha1 prefixes over every source the library is built from (lpcnet_amd/csrc/*, the public headers, the
+    compile flags) and over the DEVICE sources alone (*.hip, *.hip.h, *.inc and the headers they include -- everything in
+    csrc/ except the host C files).  Both are baked into the library (lpcnet_hip_build_info()); `dev` ties a rocprofv3
+    measurement under profiles/ to the kernels it was taken with (bench.py: kernel_source_hash), so a change to host code
+    alone does not orphan the profiles."""
+    import hashlib
+    hs, hd = hashlib.sha1(), hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith((".h", ".hip", ".inc", ".c")):
+            continue
+        data = f.encode() + open(os.path.join(CSRC, f), "rb").read()
+        hs.update(data)
+        if not f.endswith(".c"):
+            hd.update(data)
+    for f in ("lpcnet.h", "lpcnet_batch.h", "lpcnet_hip_state.h"):
+        hs.update(f.encode() + open(os.path.join(HERE, "..", "include", f), "rb").read())
+    flags = " ".join(x for x in HIP_FLAGS if not x.startswith("-I")) + " | " + " ".join(extra_flags)
+    hs.update((flags + " | " + " ".join(x for x in C_FLAGS if not x.startswith("-I"))).encode())
+    hd.update(flags.encode())
+    return hs.hexdigest()[:16], hd.hexdigest()[:16]
+
+
+def baked_hashes(lib):
+    """The (src, dev) hashes a built library carries, read from the file without loading it (None if absent / older build)."""
+    try:
+        data = open(lib, "rb").read()
+    except OSError:
+        return None
+    i = data.find(b"LPCN_BUILD_INFO: src=")
+    if i < 0:
+        return None
+    txt = data[i:i + 96].split(b"\0", 1)[0].decode(errors="replace")
+    try:
+        kv = dict(x.split("=", 1) for x in txt.split()[1:])
+        return kv["src"], kv["dev"]
+    except Exception:
+        return None
 
 
 def build(force=False, verbose=True, prof=False):
     """prof=True builds liblpcnet_hip_prof.so with the in-kernel phase profiler compiled in
-    (tools only; select it with LPCNET_HIP_LIB=<path>)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    srcs += [os.path.join(HERE, "..", "include", f) for f in ("lpcnet.h", "lpcnet_batch.h")]
+    (tools only; select it with LPCNET_HIP_LIB=<path>).  A library is up to date when the source hash it carries equals
+    the tree's (not by file times: the .so travels to the GPU box prebuilt, and the hash is what proves it matches)."""
     lib = LIB.replace(".so", "_prof.so") if prof else LIB
-    if not force and not _newer(lib, srcs):
+    pf = ["-DLPCN_ENABLE_PROF=1"] + (["-DLPCN_PROF_MASK=" + os.environ["LPCN_PROF_MASK"]] if "LPCN_PROF_MASK" in os.environ else []) if prof else []
+    extra = os.environ.get("LPCN_EXTRA_FLAGS", "").split()
+    h_src, h_dev = source_hashes(pf + extra)
+    if not force and baked_hashes(lib) == (h_src, h_dev):
         return lib
     objdir = os.path.join(HERE, "build_prof" if prof else "build")
     os.makedirs(objdir, exist_ok=True)
@@ -49,8 +84,6 @@ def build(force=False, verbose=True, prof=False):
         subprocess.check_call(cmd)
 
     # engine.hip + the sample kernel's variants, one translation unit per streams-per-workgroup value: built in parallel
-    pf = ["-DLPCN_ENABLE_PROF=1"] + (["-DLPCN_PROF_MASK=" + os.environ["LPCN_PROF_MASK"]] if "LPCN_PROF_MASK" in os.environ else []) if prof else []
-    extra = os.environ.get("LPCN_EXTRA_FLAGS", "").split()
     jobs = [([HIPCC] + HIP_FLAGS + pf + extra + ["-c", os.path.join(CSRC, "engine.hip"), "-o", os.path.join(objdir, "engine.o")])]
     for sv in (1, 2, 4):
         jobs.append([HIPCC] + HIP_FLAGS + pf + extra + [f"-DLPCN_S={sv}", "-c", os.path.join(CSRC, "sample_variants.hip"), "-o", os.path.join(objdir, f"sample_s{sv}.o")])
@@ -60,9 +93,31 @@ def build(force=False, verbose=True, prof=False):
     objs += [j[-1] for j in jobs]
     for c in ("api.c", "model_pack.c"):
         o = os.path.join(objdir, c[:-2] + ".o")
-        run(["gcc"] + C_FLAGS + ["-c", os.path.join(CSRC, c), "-o", o])
+        run(["gcc"] + C_FLAGS + [f'-DLPCN_SOURCE_HASH="{h_src}"', f'-DLPCN_DEVICE_SOURCE_HASH="{h_dev}"', "-c", os.path.join(CSRC, c), "-o", o])
         objs.append(o)
     run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread", "-lm"])
+    return lib
+
+
+def build_small_registry(verbose=False):
+    """liblpcnet_hip_smallreg.so: the same objects with a model registry of 4 slots / 2 resident device sides (api.c rebuilt with
+    -DLPCN_MAX_MODELS=4 -DLPCN_MAX_RESIDENT=2), so that tests reach the eviction paths that need > 256 distinct models in the product
+    build (tests/test_gpu_wide.py; select with LPCNET_HIP_LIB).  Test artefact, git-ignored like every built library."""
+    build(verbose=verbose)
+    lib = LIB.replace(".so", "_smallreg.so")
+    h_src, h_dev = source_hashes()
+    if baked_hashes(lib) == (h_src + "-smallreg", h_dev):
+        return lib
+    objdir = os.path.join(HERE, "build")
+    o = os.path.join(objdir, "api_smallreg.o")
+    cmds = [["gcc"] + C_FLAGS + ["-DLPCN_MAX_MODELS=4", "-DLPCN_MAX_RESIDENT=2", f'-DLPCN_SOURCE_HASH="{h_src}-smallreg"', f'-DLPCN_DEVICE_SOURCE_HASH="{h_dev}"',
+                                 "-c", os.path.join(CSRC, "api.c"), "-o", o],
+            [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + [os.path.join(objdir, f) for f in ("engine.o", "sample_s1.o", "sample_s2.o", "sample_s4.o")]
+            + [o, os.path.join(objdir, "model_pack.o"), "-lpthread", "-lm"]]
+    for c in cmds:
+        if verbose:
+            print(" ".join(c), flush=True)
+        subprocess.check_call(c)
     return lib
 
 

@@ -79,15 +79,34 @@ struct LPCNetBatch {
 };
 
 static __thread char tl_err[512];
+static __thread int tl_status;        /* sticky: code of the first failed void entry point on this thread since lpcnet_hip_clear_error() */
 static void set_err(const char *msg) { snprintf(tl_err, sizeof(tl_err), "%s", msg); }
 static void take_engine_err(void) { snprintf(tl_err, sizeof(tl_err), "%s", lpcn_last_error()); }
 const char *lpcnet_hip_last_error(void) { return tl_err; }
 const char *lpcnet_batch_last_error(void) { return tl_err; }
+int lpcnet_hip_status(void) { return tl_status; }
+void lpcnet_hip_clear_error(void) { tl_status = 0; tl_err[0] = 0; }
+
+#ifndef LPCN_SOURCE_HASH
+#define LPCN_SOURCE_HASH "unknown"
+#endif
+#ifndef LPCN_DEVICE_SOURCE_HASH
+#define LPCN_DEVICE_SOURCE_HASH "unknown"
+#endif
+/* identity of the sources this library was built from (lpcnet_amd/build.py bakes both in; the marker makes the string
+ * findable in the file without loading it): src = every file under csrc/ + include/, dev = the device sources only */
+static const char g_build_info[] = "LPCN_BUILD_INFO: src=" LPCN_SOURCE_HASH " dev=" LPCN_DEVICE_SOURCE_HASH;
+const char *lpcnet_hip_build_info(void) { return g_build_info + sizeof("LPCN_BUILD_INFO: ") - 1; }
 
 /* ---- VQ codebooks for the codec path (absent generated file ceps_codebooks.c) ---------------- */
 static float *g_cb[4];
 static int g_cb_version;              /* bumped by every lpcnet_hip_set_codebooks: batches re-upload lazily */
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;      /* model registry */
+/* The codebooks have a lock of their own, and readers share it: decoder threads unpack their packets concurrently (the
+ * per-stream VQ memory lives in the caller's LPCNetDecState) and never meet the registry lock; only
+ * lpcnet_hip_set_codebooks() -- and the one-time lookup of the default file -- excludes them. */
+static pthread_rwlock_t g_cb_lock = PTHREAD_RWLOCK_INITIALIZER;
+static int g_cb_default_tried;
 
 static const size_t g_cb_count[4] = {1024 * 17, 1024 * 17, 1024 * 17, 4096 * 18};
 
@@ -107,9 +126,9 @@ static int install_codebooks_locked(const float *const src[4])
 void lpcnet_hip_set_codebooks(const float *cb1, const float *cb2, const float *cb3, const float *cbd)
 {
     const float *const src[4] = {cb1, cb2, cb3, cbd};
-    pthread_mutex_lock(&g_lock);
+    pthread_rwlock_wrlock(&g_cb_lock);
     if (install_codebooks_locked(src) != 0) set_err("lpcnet_hip_set_codebooks: out of memory");
-    pthread_mutex_unlock(&g_lock);
+    pthread_rwlock_unlock(&g_cb_lock);
 }
 
 /* whole file into malloc'ed memory (NULL if absent / unreadable / empty) */
@@ -132,9 +151,8 @@ static unsigned char *read_file(const char *path, long *len)
  * raw little-endian float32: ceps_codebook1..3 [1024][17] each, then ceps_codebook_diff4 [4096][18]. */
 static void default_codebooks_locked(void)
 {
-    static int tried;
-    if (g_cb[0] || tried) return;
-    tried = 1;
+    if (g_cb[0] || g_cb_default_tried) return;
+    g_cb_default_tried = 1;
     const char *path = getenv("LPCNET_HIP_CODEBOOKS");
     long len = 0;
     unsigned char *buf = read_file(path && *path ? path : "ceps_codebooks.bin", &len);
@@ -146,6 +164,18 @@ static void default_codebooks_locked(void)
         (void)install_codebooks_locked(src);
     }
     free(buf);
+}
+
+/* the codebooks, read-locked (shared); the default file is looked for once, under the write lock */
+static void codebooks_rdlock(void)
+{
+    pthread_rwlock_rdlock(&g_cb_lock);
+    if (g_cb[0] || g_cb_default_tried) return;
+    pthread_rwlock_unlock(&g_cb_lock);
+    pthread_rwlock_wrlock(&g_cb_lock);
+    default_codebooks_locked();
+    pthread_rwlock_unlock(&g_cb_lock);
+    pthread_rwlock_rdlock(&g_cb_lock);
 }
 
 /* packet -> 4 feature vectors.  Follows src/lpcnet_dec.c:81-155 and src/common.c:37-65:
@@ -163,10 +193,9 @@ static void band_interp(float *x, const float *left, const float *right, int mod
         x[i] = mode == 0 ? .5f * (left[i] + right[i]) : (mode == 1 ? left[i] : right[i]);
 }
 
-/* (called with g_lock held: the codebooks may be replaced by another thread) */
+/* (called with the codebooks read-locked, codebooks_rdlock(): another thread may replace them) */
 static int packet_to_features(float feat[4][NB_TOTAL_FEATURES], float *vq_mem, const unsigned char *buf)
 {
-    default_codebooks_locked();
     if (!g_cb[0]) return -1;
     int pos = 0;
     const int c0_id = (int)get_bits(buf, &pos, 7), main_pitch = (int)get_bits(buf, &pos, 6);
@@ -230,6 +259,7 @@ typedef struct {
     pthread_cond_t q_cv;
     struct comb_req *q_head, *q_tail;
     int q_leader;                     /* a caller is dispatching (on the device or about to) */
+    int fail_code, fail_count;        /* sticky: first failed pass on this model (lpcnet_hip_model_status) */
 } registry_entry;
 #define COMB_MAX 256
 /* one waiting lpcnet_synthesize call */
@@ -237,9 +267,17 @@ typedef struct comb_req {
     LPCNetState *st; const float *feat; short *pcm; int N;
     int done, rc;
     struct comb_req *next;
+    char err[256];                    /* the leader's message for this caller (tl_err is thread-local) */
 } comb_req;
-#define MAX_MODELS 256
-#define MAX_RESIDENT 16
+#ifndef LPCN_MAX_MODELS
+#define LPCN_MAX_MODELS 256           /* slots (the handle's low byte); tests build a library with a handful to reach the eviction paths */
+#endif
+#ifndef LPCN_MAX_RESIDENT
+#define LPCN_MAX_RESIDENT 16          /* slots that hold a device side at the same time */
+#endif
+#define MAX_MODELS LPCN_MAX_MODELS
+#define MAX_RESIDENT LPCN_MAX_RESIDENT
+_Static_assert(MAX_MODELS >= 2 && MAX_MODELS <= 256 && MAX_RESIDENT >= 1, "the handle keeps the slot in its low byte");
 static registry_entry g_reg[MAX_MODELS];
 static int g_device = -1;             /* device of the single-stream API: lpcnet_hip_set_device(), $LPCNET_HIP_DEVICE, else 0 */
 static int g_default_model = -1;      /* handle of the process-default model, -1 = not resolved yet */
@@ -324,7 +362,7 @@ static int registry_bind(const unsigned char *blob, int len)
     }
     if (slot < 0) {                                          /* table full: evict the least recently used slot that nobody is running on */
         for (int i = 0; i < MAX_MODELS; i++)
-            if (__atomic_load_n(&g_reg[i].pins, __ATOMIC_SEQ_CST) == 0 && i != (g_default_model & 0xFF) && (slot < 0 || g_reg[i].last_use < g_reg[slot].last_use) &&
+            if (__atomic_load_n(&g_reg[i].pins, __ATOMIC_SEQ_CST) == 0 && i != handle_slot(g_default_model) && (slot < 0 || g_reg[i].last_use < g_reg[slot].last_use) &&
                 pthread_mutex_trylock(&g_reg[i].run_lock) == 0) {
                 if (slot >= 0) pthread_mutex_unlock(&g_reg[slot].run_lock);
                 slot = i;
@@ -466,17 +504,42 @@ int lpcnet_hip_decoder_load_model(LPCNetDecState *st, const unsigned char *data,
     return lpcnet_load_model(&st->lpcnet_state, data, len);
 }
 
-/* The registry slot this state runs on, PINNED (neither evicted nor recycled until unpinned) but not locked: resolves the
- * handle / the default model and makes sure the slot has a device side.  Only g_lock is taken. */
-static registry_entry *pin_entry(LPCNetState *st, const char *who)
+/* ---- failure of an entry point that returns void in the reference (SURVEY.md §8b "Errors") -------------------------------
+ * The reference's lpcnet_synthesize & co. cannot fail; here a device can.  Such a call does NOT abort the process: it
+ * zero-fills what it was asked to produce (silence / zero frame products), leaves the caller's state as it was, and records
+ * the failure in a sticky per-thread status (lpcnet_hip_status(), message in lpcnet_hip_last_error(), until
+ * lpcnet_hip_clear_error()) and a sticky per-model status (lpcnet_hip_model_status()).  Under the combining dispatcher every
+ * caller of a failed pass gets its own zero-filled output and its own status.  The first few failures of a process are also
+ * written to stderr (LPCNET_HIP_QUIET=1: never); LPCNET_HIP_ABORT_ON_ERROR=1 restores the old stop-with-a-message. */
+static void entry_failed(const char *who, int code, registry_entry *r, const char *msg)
 {
-    pthread_mutex_lock(&g_lock);
+    char buf[sizeof(tl_err)];
+    snprintf(buf, sizeof(buf), "%s: %s", who, msg ? msg : "");
+    snprintf(tl_err, sizeof(tl_err), "%s", buf);
+    if (!tl_status) tl_status = code;
+    if (r) {
+        int zero = 0;
+        __atomic_compare_exchange_n(&r->fail_code, &zero, code, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+        __atomic_add_fetch(&r->fail_count, 1, __ATOMIC_SEQ_CST);
+    }
+    static int reported;
+    const char *ab = getenv("LPCNET_HIP_ABORT_ON_ERROR");
+    const int fatal = ab && *ab == '1';
+    if (fatal || (!getenv("LPCNET_HIP_QUIET") && __atomic_fetch_add(&reported, 1, __ATOMIC_SEQ_CST) < 8))
+        fprintf(stderr, "%s%s\n", tl_err, fatal ? "" : " -- output zero-filled, see lpcnet_hip_status()");
+    if (fatal) abort();
+}
+
+/* (g_lock held) registry slot of this state's model -- its own handle, else the process-default model -- with a device
+ * side; -1 with *code and tl_err set.  `msg` receives the explanation (the engine's message is thread-local too). */
+static int resolve_slot_locked(LPCNetState *st, int *code)
+{
     int h = (st->magic == LPCN_MAGIC) ? st->model_id : -1;
     if (h >= 0 && handle_slot(h) < 0) {
-        pthread_mutex_unlock(&g_lock);
-        fprintf(stderr, "%s: the model bound to this state was evicted (more than %d distinct models bound in this process); "
-                        "call lpcnet_load_model again\n", who, MAX_MODELS);
-        abort();
+        snprintf(tl_err, sizeof(tl_err), "the model bound to this state was evicted (more than %d distinct models bound in this process); "
+                                         "call lpcnet_load_model again", MAX_MODELS);
+        *code = LPCN_E_MODEL;
+        return -1;
     }
     if (h < 0) {
         h = default_model_locked();
@@ -484,12 +547,23 @@ static registry_entry *pin_entry(LPCNetState *st, const char *who)
     }
     const int id = handle_slot(h);
     if (id < 0 || registry_materialize(&g_reg[id]) != 0) {
-        pthread_mutex_unlock(&g_lock);
-        fprintf(stderr, "%s: no model bound to this state and no default model (lpcnet_load_model, lpcnet_hip_set_default_model, "
-                        "$LPCNET_HIP_MODEL or ./weights_blob.bin): %s; the HIP engine has no built-in model and no CPU fallback\n",
-                who, tl_err[0] ? tl_err : "none found");
-        abort();
+        char why[256];
+        snprintf(why, sizeof(why), "%.255s", (id >= 0 && tl_err[0]) ? tl_err : "none found");
+        snprintf(tl_err, sizeof(tl_err), "no model bound to this state and no default model (lpcnet_load_model, lpcnet_hip_set_default_model, "
+                                         "$LPCNET_HIP_MODEL or ./weights_blob.bin): %s; the HIP engine has no built-in model and no CPU fallback", why);
+        *code = id >= 0 ? LPCN_E_HIP : LPCN_E_MODEL;
+        return -1;
     }
+    return id;
+}
+
+/* The registry slot this state runs on, PINNED (neither evicted nor recycled until unpinned) but not locked: resolves the
+ * handle / the default model and makes sure the slot has a device side.  Only g_lock is taken.  NULL: *code, tl_err. */
+static registry_entry *pin_entry(LPCNetState *st, int *code)
+{
+    pthread_mutex_lock(&g_lock);
+    const int id = resolve_slot_locked(st, code);
+    if (id < 0) { pthread_mutex_unlock(&g_lock); return NULL; }
     registry_entry *r = &g_reg[id];
     r->last_use = ++g_use_clock;
     __atomic_add_fetch(&r->pins, 1, __ATOMIC_SEQ_CST);
@@ -498,48 +572,33 @@ static registry_entry *pin_entry(LPCNetState *st, const char *who)
 }
 static void unpin_entry(registry_entry *r) { __atomic_sub_fetch(&r->pins, 1, __ATOMIC_SEQ_CST); }
 
-/* The registry slot this state runs on, locked for one device round trip (unlock with release_entry). */
-static registry_entry *acquire_entry(LPCNetState *st, const char *who)
+/* A PINNED slot, locked for one device round trip (unlock with release_entry).  The lock is taken BY SLOT: the caller's
+ * queue, model and device side are this slot's whatever the state's handle or the default model have become meanwhile
+ * (ADVICE r4).  lpcnet_hip_shutdown() may have released the device side while we waited: it is re-created (lock order
+ * g_lock -> run_lock everywhere).  0, or a negative code with tl_err set. */
+static int acquire_slot(registry_entry *r)
 {
     for (;;) {
         pthread_mutex_lock(&g_lock);
-        int h = (st->magic == LPCN_MAGIC) ? st->model_id : -1;
-        if (h >= 0 && handle_slot(h) < 0) {
-            pthread_mutex_unlock(&g_lock);
-            fprintf(stderr, "%s: the model bound to this state was evicted (more than %d distinct models bound in this process); "
-                            "call lpcnet_load_model again\n", who, MAX_MODELS);
-            abort();
-        }
-        if (h < 0) {
-            h = default_model_locked();
-            if (h >= 0 && st->magic == LPCN_MAGIC) st->model_id = h;
-        }
-        const int id = handle_slot(h);
-        if (id < 0 || registry_materialize(&g_reg[id]) != 0) {
-            pthread_mutex_unlock(&g_lock);
-            fprintf(stderr, "%s: no model bound to this state and no default model (lpcnet_load_model, lpcnet_hip_set_default_model, "
-                            "$LPCNET_HIP_MODEL or ./weights_blob.bin): %s; the HIP engine has no built-in model and no CPU fallback\n",
-                    who, tl_err[0] ? tl_err : "none found");
-            abort();
-        }
-        registry_entry *r = &g_reg[id];
-        r->last_use = ++g_use_clock;
-        __atomic_add_fetch(&r->pins, 1, __ATOMIC_SEQ_CST);   /* keeps the slot from being evicted while we wait for it */
-        pthread_mutex_unlock(&g_lock);                       /* (other models, the decoder's packet unpacking, lpcnet_load_model go on meanwhile) */
+        const int rc = registry_materialize(r);
+        pthread_mutex_unlock(&g_lock);
+        if (rc) return LPCN_E_HIP;
         pthread_mutex_lock(&r->run_lock);
-        /* (lock order is g_lock -> run_lock everywhere, so g_lock is not taken again here: the pin is dropped atomically) */
-        __atomic_sub_fetch(&r->pins, 1, __ATOMIC_SEQ_CST);
-        if (__atomic_load_n(&r->dev, __ATOMIC_SEQ_CST) != NULL) return r;     /* lpcnet_hip_shutdown() may have released the device side while we waited */
+        if (__atomic_load_n(&r->dev, __ATOMIC_SEQ_CST) != NULL) return 0;
         pthread_mutex_unlock(&r->run_lock);
     }
 }
-static void release_entry(registry_entry *r) { pthread_mutex_unlock(&r->run_lock); }
-
-static void device_failure(const char *who)
+/* The registry slot this state runs on, locked for one device round trip; NULL: *code, tl_err. */
+static registry_entry *acquire_entry(LPCNetState *st, int *code)
 {
-    fprintf(stderr, "%s: device failure: %s\n", who, lpcn_last_error());
-    abort();
+    registry_entry *r = pin_entry(st, code);                 /* (the pin keeps the slot from being evicted while we wait for it) */
+    if (!r) return NULL;
+    const int rc = acquire_slot(r);
+    unpin_entry(r);                                          /* (run_lock held: the slot is neither recycled nor evicted under it) */
+    if (rc) { *code = rc; return NULL; }
+    return r;
 }
+static void release_entry(registry_entry *r) { pthread_mutex_unlock(&r->run_lock); }
 
 /* upload the caller's POD state unless it is the copy the device already holds */
 static int push_state(registry_entry *r, const lpcn_stream_state *s)
@@ -555,6 +614,18 @@ static int pull_state(registry_entry *r, lpcn_stream_state *s)
     return rc;
 }
 
+/* sticky status of the model a state is bound to (0, or the code of its first failed pass since the last clear) */
+int lpcnet_hip_model_status(const LPCNetState *st, int clear)
+{
+    if (!st || st->magic != LPCN_MAGIC) return LPCN_E_ARG;
+    pthread_mutex_lock(&g_lock);
+    const int slot = handle_slot(st->model_id >= 0 ? st->model_id : g_default_model);
+    int code = slot < 0 ? LPCN_E_MODEL : __atomic_load_n(&g_reg[slot].fail_code, __ATOMIC_SEQ_CST);
+    if (slot >= 0 && clear) __atomic_store_n(&g_reg[slot].fail_code, 0, __ATOMIC_SEQ_CST);
+    pthread_mutex_unlock(&g_lock);
+    return code;
+}
+
 /* ---- the reference's internal entry points (src/lpcnet_private.h:125-132), which src/lpcnet_plc.c links to ---- */
 
 /* src/lpcnet.c:226-233 */
@@ -567,18 +638,43 @@ void lpcnet_reset_signal(LPCNetState *st)
     memset(st->s.gru_b, 0, sizeof(st->s.gru_b));
 }
 
-/* src/lpcnet.c:82-120: one step of the 100 Hz network; products go to the caller's arrays */
-void run_frame_network(LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features)
+/* src/lpcnet.c:82-120: one step of the 100 Hz network; products go to the caller's arrays.  0 or a negative code (the
+ * caller's state is untouched and nothing is written on failure). */
+static int frame_network_rc(LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features,
+                            registry_entry **rout)
 {
-    registry_entry *r = acquire_entry(st, "run_frame_network");
+    int code = 0;
+    registry_entry *r = acquire_entry(st, &code);
+    *rout = r;
+    if (!r) return code;
     float lpc_new[LPCN_LPC_ORDER];      /* `lpc` may point into st->s, which the state download overwrites */
+    float ga[LPCN_ROWS_A], gb[LPCN_ROWS_B];
+    lpcn_stream_state snew;
     int rc = push_state(r, &st->s);
     r->cache_valid = 0;
-    if (!rc) rc = lpcn_batch_dev_run_frames_host(r->dev, features, NB_FEATURES, gru_a_condition, gru_b_condition, lpc_new, 1);
-    if (!rc) rc = pull_state(r, &st->s);
+    if (!rc) rc = lpcn_batch_dev_run_frames_host(r->dev, features, NB_FEATURES, ga, gb, lpc_new, 1);
+    if (!rc) rc = pull_state(r, &snew);
+    if (rc) { r->cache_valid = 0; take_engine_err(); }
     release_entry(r);
-    if (rc) device_failure("run_frame_network");
+    if (rc) return rc;
+    st->s = snew;
+    memcpy(gru_a_condition, ga, sizeof(ga));
+    memcpy(gru_b_condition, gb, sizeof(gb));
     memcpy(lpc, lpc_new, sizeof(lpc_new));
+    return 0;
+}
+void run_frame_network(LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features)
+{
+    registry_entry *r = NULL;
+    const int rc = frame_network_rc(st, gru_a_condition, gru_b_condition, lpc, features, &r);
+    if (rc) {
+        char why[sizeof(tl_err)];
+        snprintf(why, sizeof(why), "%s", tl_err);
+        memset(gru_a_condition, 0, sizeof(float) * LPCN_ROWS_A);
+        memset(gru_b_condition, 0, sizeof(float) * LPCN_ROWS_B);
+        memset(lpc, 0, sizeof(float) * LPCN_LPC_ORDER);
+        entry_failed("run_frame_network", rc, r, why);
+    }
 }
 
 /* src/lpcnet.c:122-132: queue a frame (at most kernel_size1 + kernel_size2 - 2 = 4, oldest dropped) */
@@ -604,49 +700,74 @@ void run_frame_network_flush(LPCNetState *st)
 
 /* src/lpcnet.c:235-271: N samples from the products held in the state; the first `preload` samples of
  * `output` are imposed on the synthesis filter (teacher forcing) instead of being written.  Any N: the
- * sample loop does not care where a call ends, so N > 160 runs as consecutive pieces of <= 160 samples. */
+ * sample loop does not care where a call ends, so N > 160 runs as consecutive pieces of <= 160 samples.
+ * On failure the samples behind the imposed ones are zero-filled and the state is left as it was. */
 void lpcnet_synthesize_tail_impl(LPCNetState *st, short *output, int N, int preload)
 {
     if (N <= 0) return;
     if (preload < 0 || preload > N) {
-        fprintf(stderr, "lpcnet_synthesize_tail_impl: preload=%d outside 0..N=%d\n", preload, N);
-        abort();
+        char why[96];
+        snprintf(why, sizeof(why), "preload=%d outside 0..N=%d", preload, N);
+        memset(output, 0, sizeof(short) * (size_t)N);
+        entry_failed("lpcnet_synthesize_tail_impl", LPCN_E_ARG, NULL, why);
+        return;
     }
-    registry_entry *r = acquire_entry(st, "lpcnet_synthesize_tail_impl");
-    int rc = push_state(r, &st->s);
-    r->cache_valid = 0;
-    for (int done = 0; !rc && done < N; done += LPCN_FRAME_SIZE) {
-        const int n = N - done < LPCN_FRAME_SIZE ? N - done : LPCN_FRAME_SIZE;
-        const int pre = preload - done < 0 ? 0 : (preload - done > n ? n : preload - done);
-        short frame[LPCN_FRAME_SIZE] = {0};
-        memcpy(frame, output + done, sizeof(short) * (size_t)pre);
-        rc = lpcn_batch_dev_set_frame_len(r->dev, n);
-        if (!rc) rc = lpcn_batch_dev_run_tail_host(r->dev, st->gru_a_condition, st->gru_b_condition, st->s.lpc, frame, 1, pre);
-        /* live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243) */
-        if (!rc) memcpy(output + done, frame, sizeof(short) * (size_t)n);
+    int code = 0;
+    registry_entry *r = acquire_entry(st, &code);
+    int rc = r ? push_state(r, &st->s) : code;
+    lpcn_stream_state snew;
+    if (r) {
+        r->cache_valid = 0;
+        for (int done = 0; !rc && done < N; done += LPCN_FRAME_SIZE) {
+            const int n = N - done < LPCN_FRAME_SIZE ? N - done : LPCN_FRAME_SIZE;
+            const int pre = preload - done < 0 ? 0 : (preload - done > n ? n : preload - done);
+            short frame[LPCN_FRAME_SIZE] = {0};
+            memcpy(frame, output + done, sizeof(short) * (size_t)pre);
+            rc = lpcn_batch_dev_set_frame_len(r->dev, n);
+            if (!rc) rc = lpcn_batch_dev_run_tail_host(r->dev, st->gru_a_condition, st->gru_b_condition, st->s.lpc, frame, 1, pre);
+            /* live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243) */
+            if (!rc) memcpy(output + done, frame, sizeof(short) * (size_t)n);
+        }
+        if (!rc) rc = pull_state(r, &snew);
+        if (rc) { r->cache_valid = 0; take_engine_err(); }
+        release_entry(r);
     }
-    if (!rc) rc = pull_state(r, &st->s);
-    release_entry(r);
-    if (rc) device_failure("lpcnet_synthesize_tail_impl");
+    if (rc) {
+        char why[sizeof(tl_err)];
+        snprintf(why, sizeof(why), "%s", tl_err);
+        memset(output + preload, 0, sizeof(short) * (size_t)(N - preload));
+        entry_failed("lpcnet_synthesize_tail_impl", rc, r, why);
+        return;
+    }
+    st->s = snew;
 }
 
 /* src/lpcnet.c:273-277 */
 void lpcnet_synthesize_impl(LPCNetState *st, const float *features, short *output, int N, int preload)
 {
-    run_frame_network(st, st->gru_a_condition, st->gru_b_condition, st->s.lpc, features);
+    registry_entry *r = NULL;
+    const int rc = frame_network_rc(st, st->gru_a_condition, st->gru_b_condition, st->s.lpc, features, &r);
+    if (rc) {                                                /* no frame products: no samples either */
+        char why[sizeof(tl_err)];
+        snprintf(why, sizeof(why), "%s", tl_err);
+        if (N > 0 && preload >= 0 && preload <= N) memset(output + preload, 0, sizeof(short) * (size_t)(N - preload));
+        entry_failed("lpcnet_synthesize_impl", rc, r, why);
+        return;
+    }
     lpcnet_synthesize_tail_impl(st, output, N, preload);
 }
 
-/* One device pass for `k` queued calls of one model (run_lock held by the caller through acquire_entry). */
+/* One device pass for `k` queued calls of one model (run_lock held by the caller through acquire_slot). */
 static int comb_run(registry_entry *r, comb_req **grp, int k)
 {
     if (k == 1) {                                            /* nobody to share with: the single-stream fast path (state upload skipped when the device copy is current) */
         comb_req *q = grp[0];
         const int fresh = !(r->cache_valid && memcmp(&r->cached, &q->st->s, sizeof(q->st->s)) == 0);
         r->cache_valid = 0;
+        lpcn_stream_state snew;
         int rc = lpcn_batch_dev_set_frame_len(r->dev, q->N);
-        if (!rc) rc = lpcn_batch_dev_run_single(r->dev, fresh ? &q->st->s : NULL, q->feat, q->pcm, &q->st->s);
-        if (!rc) { r->cached = q->st->s; r->cache_valid = 1; }
+        if (!rc) rc = lpcn_batch_dev_run_single(r->dev, fresh ? &q->st->s : NULL, q->feat, q->pcm, &snew);
+        if (!rc) { q->st->s = snew; r->cached = snew; r->cache_valid = 1; }
         return rc;
     }
     if (!r->gdev) {
@@ -659,7 +780,7 @@ static int comb_run(registry_entry *r, comb_req **grp, int k)
     short *pc[COMB_MAX];
     for (int i = 0; i < k; i++) { sin[i] = &grp[i]->st->s; sout[i] = &grp[i]->st->s; ft[i] = grp[i]->feat; pc[i] = grp[i]->pcm; }
     r->cache_valid = 0;                                      /* (the one-stream batch's device copy is not what these states continue from) */
-    return lpcn_batch_dev_run_group(r->gdev, k, grp[0]->N, sin, ft, pc, sout);
+    return lpcn_batch_dev_run_group(r->gdev, k, grp[0]->N, sin, ft, pc, sout);      /* (writes states and PCM only after the pass has succeeded) */
 }
 
 /* src/lpcnet.c:279-281.  N <= 160 (every caller in the reference): one fused device pass -- frame kernels and sample
@@ -672,14 +793,16 @@ static int comb_run(registry_entry *r, comb_req **grp, int k)
  * with its own N (up to COMB_MAX), and runs them as ONE multi-stream pass (each caller's POD state up, frame + sample
  * kernels, states and PCM down); calls that arrive meanwhile queue up and form the next pass, led by one of them -- group
  * commit, no timer: a lone caller never waits for company, and under load a pass carries as many streams as arrived during
- * the previous one.  Results are bit-identical to running the calls one by one (streams are independent). */
-void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)
+ * the previous one.  Results are bit-identical to running the calls one by one (streams are independent).
+ * Returns 0 or a negative code (tl_err set; *rout = the slot, if one was resolved); nothing is written on failure. */
+static int synthesize_rc(LPCNetState *st, const float *features, short *output, int N, registry_entry **rout)
 {
-    if (N <= 0) return;
-    if (N > LPCN_FRAME_SIZE) { lpcnet_synthesize_impl(st, features, output, N, 0); return; }
     /* the slot of this state's model, pinned while the call is queued (a pinned slot is neither evicted nor recycled) */
-    registry_entry *r = pin_entry(st, "lpcnet_synthesize");      /* (g_lock only: a pass in flight on this model must not keep other callers from queueing) */
-    comb_req me = {st, features, output, N, 0, 0, NULL};
+    int code = 0;
+    registry_entry *r = pin_entry(st, &code);                /* (g_lock only: a pass in flight on this model must not keep other callers from queueing) */
+    *rout = r;
+    if (!r) return code;
+    comb_req me = {st, features, output, N, 0, 0, NULL, {0}};
     pthread_mutex_lock(&r->q_lock);
     if (r->q_tail) r->q_tail->next = &me; else r->q_head = &me;
     r->q_tail = &me;
@@ -700,17 +823,39 @@ void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, in
         }
         r->q_tail = last;
         pthread_mutex_unlock(&r->q_lock);
-        registry_entry *r2 = acquire_entry(st, "lpcnet_synthesize");      /* run_lock; re-creates the device side if it was released meanwhile */
-        int rc = comb_run(r2, grp, k);
-        release_entry(r2);
+        int rc = acquire_slot(r);                            /* run_lock of THIS slot; re-creates the device side if it was released meanwhile */
+        if (!rc) {
+            rc = comb_run(r, grp, k);
+            if (rc) { r->cache_valid = 0; take_engine_err(); }
+            release_entry(r);
+        }
         pthread_mutex_lock(&r->q_lock);
-        for (int i = 0; i < k; i++) { grp[i]->rc = rc; grp[i]->done = 1; }
+        for (int i = 0; i < k; i++) {
+            grp[i]->rc = rc;
+            if (rc) snprintf(grp[i]->err, sizeof(grp[i]->err), "%.255s", tl_err);      /* (the message is thread-local: hand every caller its copy) */
+            grp[i]->done = 1;
+        }
         r->q_leader = 0;
         pthread_cond_broadcast(&r->q_cv);
     }
     pthread_mutex_unlock(&r->q_lock);
     unpin_entry(r);
-    if (me.rc) device_failure("lpcnet_synthesize");
+    if (me.rc) snprintf(tl_err, sizeof(tl_err), "%s", me.err);
+    return me.rc;
+}
+
+void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)
+{
+    if (N <= 0) return;
+    if (N > LPCN_FRAME_SIZE) { lpcnet_synthesize_impl(st, features, output, N, 0); return; }
+    registry_entry *r = NULL;
+    const int rc = synthesize_rc(st, features, output, N, &r);
+    if (rc) {
+        char why[sizeof(tl_err)];
+        snprintf(why, sizeof(why), "%s", tl_err);
+        memset(output, 0, sizeof(short) * (size_t)N);
+        entry_failed("lpcnet_synthesize", rc, r, why);
+    }
 }
 
 /* ---- decoder ----------------------------------------------------------------------------------- */
@@ -732,18 +877,29 @@ LPCNetDecState *lpcnet_decoder_create(void)
 
 void lpcnet_decoder_destroy(LPCNetDecState *st) { free(st); }
 
+/* src/lpcnet.c:310-319.  -1 (the reference always returns 0) when no codebooks are installed or a frame's device pass
+ * failed -- the packet's remaining samples are zero-filled in that case. */
 int lpcnet_decode(LPCNetDecState *st, const unsigned char *buf, short *pcm)
 {
     float feat[4][NB_TOTAL_FEATURES];
-    pthread_mutex_lock(&g_lock);
+    codebooks_rdlock();                                      /* shared: decoder threads unpack concurrently, the VQ memory is the caller's */
     const int rc = packet_to_features(feat, st->vq_mem, buf);
-    pthread_mutex_unlock(&g_lock);
+    pthread_rwlock_unlock(&g_cb_lock);
     if (rc != 0) {
         set_err("lpcnet_decode: no VQ codebooks installed (lpcnet_hip_set_codebooks, $LPCNET_HIP_CODEBOOKS or ./ceps_codebooks.bin)");
         return -1;
     }
-    for (int k = 0; k < 4; k++)
-        lpcnet_synthesize(&st->lpcnet_state, feat[k], &pcm[k * LPCN_FRAME_SIZE], LPCN_FRAME_SIZE);
+    for (int k = 0; k < 4; k++) {
+        registry_entry *r = NULL;
+        const int rs = synthesize_rc(&st->lpcnet_state, feat[k], &pcm[k * LPCN_FRAME_SIZE], LPCN_FRAME_SIZE, &r);
+        if (rs) {
+            char why[sizeof(tl_err)];
+            snprintf(why, sizeof(why), "%s", tl_err);
+            memset(&pcm[k * LPCN_FRAME_SIZE], 0, sizeof(short) * (size_t)(4 - k) * LPCN_FRAME_SIZE);
+            entry_failed("lpcnet_decode", rs, r, why);
+            return -1;
+        }
+    }
     return 0;
 }
 
@@ -939,16 +1095,15 @@ int lpcnet_batch_sync(LPCNetBatch *b)
 /* the device copies of the VQ codebooks follow lpcnet_hip_set_codebooks() */
 static int batch_codebooks(LPCNetBatch *b)
 {
-    pthread_mutex_lock(&g_lock);
+    codebooks_rdlock();
     int rc = 0;
-    default_codebooks_locked();
     if (!g_cb[0]) { set_err("lpcnet_batch_decode: no VQ codebooks installed (lpcnet_hip_set_codebooks)"); rc = LPCN_E_MODEL; }
     for (int k = 0; !rc && k < b->n_shards; k++)
         if (b->sh[k].cb_version != g_cb_version) {
             rc = lpcn_engine_set_codebooks(b->sh[k].engine, g_cb[0], g_cb[1], g_cb[2], g_cb[3]);
             if (rc) take_engine_err(); else b->sh[k].cb_version = g_cb_version;
         }
-    pthread_mutex_unlock(&g_lock);
+    pthread_rwlock_unlock(&g_cb_lock);
     return rc;
 }
 
@@ -1102,6 +1257,13 @@ int lpcnet_hip_exp10_device(const float *x, double *out, int n)
 {
     if (!x || !out || n <= 0) { set_err("lpcnet_hip_exp10_device: bad arguments"); return LPCN_E_ARG; }
     FWD(lpcn_debug_exp10(single_stream_device(), x, out, (size_t)n));
+}
+
+/* test seam (include/lpcnet_batch.h): the arithmetic identities the PARITY kernels rest on, on the device */
+int lpcnet_hip_arith_identities_device(const float *a, const float *b, unsigned *out_mfma, unsigned *out_mul, unsigned *out_pk, unsigned *out_sc, int n)
+{
+    if (!a || !b || !out_mfma || !out_mul || !out_pk || !out_sc || n <= 0) { set_err("lpcnet_hip_arith_identities_device: bad arguments"); return LPCN_E_ARG; }
+    FWD(lpcn_debug_arith_identities(single_stream_device(), a, b, out_mfma, out_mul, out_pk, out_sc, (size_t)n));
 }
 
 /* Host-only model check (no GPU needed): parses the blob with the loader's rules, builds the device

@@ -610,8 +610,10 @@ extern "C" int lpcn_batch_dev_tune(lpcn_batch_dev *b)
     return order_end(b, st);
 }
 
-extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, int feat_stride,
-                                  short *d_pcm, int n_frames, int preload, void *hip_stream)
+// may_tune: the call may measure the streams per workgroup first (allocates, synchronises, launches trial kernels).  Only the
+// host-pointer wrappers pass true; the enqueue-only device-pointer entry points never do, whichever stream they name (ADVICE r4:
+// a NULL hip_stream used to select the engine's own stream AND the measurement).
+static int run_impl(lpcn_batch_dev *b, const float *d_features, int feat_stride, short *d_pcm, int n_frames, int preload, void *hip_stream, bool may_tune)
 {
     if (n_frames <= 0 || feat_stride < LPCN_NB_FEAT || preload < 0 || preload > LPCN_FRAME_SIZE) {
         snprintf(g_err, sizeof(g_err), "bad run arguments"); return LPCN_E_ARG;
@@ -621,7 +623,7 @@ extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, in
     float tf = 0.f, ts = 0.f;
     { int rco = order_begin(b, st); if (rco) return rco; }
     if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (the step call's per-stream frame products are stale now)
-    if (b->S_auto && !b->tuned && st == b->e->stream) { int rct = autotune_streams_per_wg(b, st); if (rct) return rct; }      // (never on a caller's stream)
+    if (b->S_auto && !b->tuned && may_tune && st == b->e->stream) { int rct = autotune_streams_per_wg(b, st); if (rct) return rct; }      // (never inside an enqueue-only call, never on a caller's stream)
     for (int f0 = 0; f0 < n_frames; f0 += b->max_chunk) {
         const int nf = n_frames - f0 < b->max_chunk ? n_frames - f0 : b->max_chunk;
         if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
@@ -641,6 +643,12 @@ extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, in
     }
     if (b->timing) { b->ms_frame = tf; b->ms_sample = ts; }
     return order_end(b, st);
+}
+
+extern "C" int lpcn_batch_dev_run(lpcn_batch_dev *b, const float *d_features, int feat_stride,
+                                  short *d_pcm, int n_frames, int preload, void *hip_stream)
+{
+    return run_impl(b, d_features, feat_stride, d_pcm, n_frames, preload, hip_stream, false);
 }
 
 static int ensure_staging(lpcn_batch_dev *b, size_t feat_floats, size_t pcm_samples)
@@ -673,7 +681,7 @@ extern "C" int lpcn_batch_dev_run_host(lpcn_batch_dev *b, const float *features,
     if ((rc = order_begin(b, st))) return rc;      // the staging buffers may still be read by work on a caller stream
     HIP_TRY(hipMemcpyAsync(b->d_feat, features, nfeat * sizeof(float), hipMemcpyHostToDevice, st));
     if (preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pcm, npcm * sizeof(short), hipMemcpyHostToDevice, st));
-    rc = lpcn_batch_dev_run(b, b->d_feat, feat_stride, b->d_pcm, n_frames, preload, st);
+    rc = run_impl(b, b->d_feat, feat_stride, b->d_pcm, n_frames, preload, st, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pcm, b->d_pcm, npcm * sizeof(short), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -701,7 +709,7 @@ extern "C" int lpcn_batch_dev_run_single(lpcn_batch_dev *b, const lpcn_stream_st
     }
     memcpy(pin + off_feat, feat, LPCN_NB_FEAT * sizeof(float));
     HIP_TRY(hipMemcpyAsync(b->d_feat, pin + off_feat, LPCN_NB_FEAT * sizeof(float), hipMemcpyHostToDevice, st));
-    rc = lpcn_batch_dev_run(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, 0, st);
+    rc = run_impl(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, 0, st, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pin, b->d_state, sizeof(lpcn_stream_state), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(pin + off_pcm, b->d_pcm, LPCN_FRAME_SIZE * sizeof(short), hipMemcpyDeviceToHost, st));
@@ -739,7 +747,7 @@ extern "C" int lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int frame_len,
     const int keepS = b->S, keep_len = b->frame_len;
     const bool keepP = b->pack2, keepA = b->S_auto, keepT = b->tuned;
     b->n = k; b->frame_len = frame_len; b->S = auto_streams_per_wg(b->e, k); b->pack2 = use_pack2(b->e, k, b->S); b->S_auto = false; b->tuned = true;
-    rc = lpcn_batch_dev_run(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, 0, st);
+    rc = run_impl(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, 0, st, false);      // (S comes from the table for the group's size)
     b->n = cap; b->frame_len = keep_len; b->S = keepS; b->pack2 = keepP; b->S_auto = keepA; b->tuned = keepT;
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pin, b->d_state, sz_st * k, hipMemcpyDeviceToHost, st));
@@ -754,7 +762,7 @@ extern "C" int lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int frame_len,
 }
 
 // Codec path: 8-byte packets [stream][packet][8] -> 4 frames each.  Device pointers, work only enqueued.
-extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
+static int decode_impl(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream, bool may_tune)
 {
     if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);      // (lpcn_batch_dev_step_host's per-stream frame products are stale now)
     if (n_packets <= 0) { snprintf(g_err, sizeof(g_err), "bad decode arguments"); return LPCN_E_ARG; }
@@ -770,7 +778,11 @@ extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_p
     hipLaunchKernelGGL(lpcn::decode_kernel, dim3((b->n + 1) / 2), dim3(64), 0, st, b->e->dec, d_packets, b->n, n_packets, b->d_vq_mem,
                        b->d_feat, LPCN_NB_FEAT);
     HIP_TRY(hipGetLastError());
-    return lpcn_batch_dev_run(b, b->d_feat, LPCN_NB_FEAT, d_pcm, T, 0, st);
+    return run_impl(b, b->d_feat, LPCN_NB_FEAT, d_pcm, T, 0, st, may_tune);
+}
+extern "C" int lpcn_batch_dev_decode(lpcn_batch_dev *b, const unsigned char *d_packets, short *d_pcm, int n_packets, void *hip_stream)
+{
+    return decode_impl(b, d_packets, d_pcm, n_packets, hip_stream, false);
 }
 
 extern "C" int lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char *packets, short *pcm, int n_packets)
@@ -790,7 +802,7 @@ extern "C" int lpcn_batch_dev_decode_host(lpcn_batch_dev *b, const unsigned char
     hipStream_t st = b->e->stream;
     if ((rc = order_begin(b, st))) return rc;
     HIP_TRY(hipMemcpyAsync(b->d_packets, packets, nbytes, hipMemcpyHostToDevice, st));
-    rc = lpcn_batch_dev_decode(b, b->d_packets, b->d_pcm, n_packets, nullptr);
+    rc = decode_impl(b, b->d_packets, b->d_pcm, n_packets, nullptr, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pcm, b->d_pcm, npcm * sizeof(short), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -949,7 +961,6 @@ extern "C" int lpcn_batch_dev_step_host(lpcn_batch_dev *b, const float *features
         if (md == 1) {
             rc = launch_frames(b, st, b->d_feat, LPCN_NB_FEAT, (size_t)LPCN_NB_FEAT, 1);
             if (!rc) {      // remember the products per stream (a later tail-only step of the stream uses them)
-                for (int i = 0; i < cnt; ++i) b->keep_ok[(size_t)map[i]] = 1;
                 hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(256), 0, st, b->d_keep_a, (const float *)b->d_cond_a, (const int *)b->d_map, cnt, LPCN_ROWS_A, 1);
                 hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_keep_b, (const float *)b->d_cond_b, (const int *)b->d_map, cnt, LPCN_ROWS_B, 1);
                 hipLaunchKernelGGL(lpcn_rows_move_kernel, dim3(cnt), dim3(64), 0, st, b->d_keep_lpc, (const float *)b->d_lpc, (const int *)b->d_map, cnt, LPCN_LPC_ORDER, 1);
@@ -966,6 +977,9 @@ extern "C" int lpcn_batch_dev_step_host(lpcn_batch_dev *b, const float *features
         if (hipGetLastError() != hipSuccess) { snprintf(g_err, sizeof(g_err), "per-stream step: kernel launch failed"); return LPCN_E_HIP; }
         HIP_TRY(hipMemcpyAsync(pc.data(), b->d_pcm, sizeof(short) * (size_t)cnt * LPCN_FRAME_SIZE, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        // only now do the group's streams own frame products a later tail-only step may continue from (the flag used to be
+        // set before the sample launch and the state scatter had succeeded)
+        if (md == 1) for (int i = 0; i < cnt; ++i) b->keep_ok[(size_t)map[i]] = 1;
         for (int i = 0; i < cnt; ++i) memcpy(pcm + (size_t)map[i] * LPCN_FRAME_SIZE, &pc[(size_t)i * LPCN_FRAME_SIZE], sizeof(short) * (size_t)N);
     }
     return 0;
@@ -1019,5 +1033,71 @@ extern "C" int lpcn_debug_exp10(int device, const float *x, double *out, size_t 
     }
     (void)hipFree(dx); (void)hipFree(dy);
     if (rc) snprintf(g_err, sizeof(g_err), "exp10 test kernel failed");
+    return rc;
+}
+
+// test seam: the arithmetic identities PARITY rests on, evaluated with THIS library's compile flags and float mode.
+//   * v_mfma_f32_4x4x1(A, B, C = -0.0): register k of lane j of a quad == v_mul_f32(A of lane k, B of lane j), bit for bit
+//     (the GRU-A items of the float PARITY kernels form their products there, sample_kernel.hip.h: mac());
+//   * each half of v_pk_mul_f32 / v_pk_add_f32 == v_mul_f32 / v_add_f32 (GRU-B's block loop, the items' sums).
+// n lanes (a multiple of 64).  out_mfma / out_mul: [n][4] bit patterns (k = 0..3: A from lane 4*(i/4) + k, B from lane i);
+// out_pk / out_sc: [n][4] = {pk_mul half 0, half 1, pk_add half 0, half 1} and the scalar instructions' results on the same operands
+// (half 0: (a[i], b[i]), half 1: (a[i^1], b[i^1])).
+__global__ void lpcn_arith_identity_kernel(const float *a, const float *b, uint32_t *out_mfma, uint32_t *out_mul, uint32_t *out_pk, uint32_t *out_sc)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    f4 negz = {-0.f, -0.f, -0.f, -0.f};
+    asm volatile("" : "+v"(negz));                         // (the same guard as the kernel's: the addend must reach the instruction as -0.0)
+    const float av = a[i], bv = b[i];
+    const f4 p = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, negz, 0, 0, 0);
+    const size_t q = i & ~(size_t)3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float ak = a[q + k], m;
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m) : "v"(ak), "v"(bv));
+        out_mfma[i * 4 + k] = __builtin_bit_cast(uint32_t, p[k]);
+        out_mul[i * 4 + k] = __builtin_bit_cast(uint32_t, m);
+    }
+    const float a2 = a[i ^ 1], b2 = b[i ^ 1];
+    f2 x = {av, a2}, y = {bv, b2}, pm, pa;
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(pm) : "v"(x), "v"(y));
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(pa) : "v"(x), "v"(y));
+    float m0, m1, s0, s1;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0) : "v"(av), "v"(bv));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1) : "v"(a2), "v"(b2));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(s0) : "v"(av), "v"(bv));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(a2), "v"(b2));
+    out_pk[i * 4 + 0] = __builtin_bit_cast(uint32_t, pm[0]); out_pk[i * 4 + 1] = __builtin_bit_cast(uint32_t, pm[1]);
+    out_pk[i * 4 + 2] = __builtin_bit_cast(uint32_t, pa[0]); out_pk[i * 4 + 3] = __builtin_bit_cast(uint32_t, pa[1]);
+    out_sc[i * 4 + 0] = __builtin_bit_cast(uint32_t, m0); out_sc[i * 4 + 1] = __builtin_bit_cast(uint32_t, m1);
+    out_sc[i * 4 + 2] = __builtin_bit_cast(uint32_t, s0); out_sc[i * 4 + 3] = __builtin_bit_cast(uint32_t, s1);
+}
+
+extern "C" int lpcn_debug_arith_identities(int device, const float *a, const float *b, uint32_t *out_mfma, uint32_t *out_mul,
+                                           uint32_t *out_pk, uint32_t *out_sc, size_t n)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { snprintf(g_err, sizeof(g_err), "no such HIP device"); return LPCN_E_NODEVICE; }
+    if (!n || n % 64) { snprintf(g_err, sizeof(g_err), "operand count must be a positive multiple of 64"); return LPCN_E_ARG; }
+    DeviceGuard guard(device);
+    float *d_in = nullptr;
+    uint32_t *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_in, 2 * n * sizeof(float)));
+    if (hipMalloc((void **)&d_out, 16 * n * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_in); snprintf(g_err, sizeof(g_err), "hipMalloc failed"); return LPCN_E_HIP; }
+    int rc = 0;
+    if (hipMemcpy(d_in, a, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_in + n, b, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = LPCN_E_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(lpcn_arith_identity_kernel, dim3((unsigned)(n / 64)), dim3(64), 0, 0, (const float *)d_in, (const float *)(d_in + n),
+                           d_out, d_out + 4 * n, d_out + 8 * n, d_out + 12 * n);
+        uint32_t *const dst[4] = {out_mfma, out_mul, out_pk, out_sc};
+        if (hipGetLastError() != hipSuccess) rc = LPCN_E_HIP;
+        for (int k = 0; k < 4 && !rc; ++k)
+            if (hipMemcpy(dst[k], d_out + (size_t)k * 4 * n, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = LPCN_E_HIP;
+    }
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (rc) snprintf(g_err, sizeof(g_err), "arithmetic identity test kernel failed");
     return rc;
 }

@@ -190,6 +190,10 @@ int  lpcn_batch_dev_profile(lpcn_batch_dev *b, unsigned long long *out);
 
 /* test seam: this engine's own 10^x (lpcnet_exp10.h) evaluated on the device for host arrays */
 int  lpcn_debug_exp10(int device, const float *x, double *out, size_t n);
+/* test seam: v_mfma_f32_4x4x1 with C = -0.0 against v_mul_f32, and the halves of v_pk_mul_f32 / v_pk_add_f32 against the scalar
+ * instructions, as bit patterns (engine.hip: lpcn_arith_identity_kernel); n = operand count, a multiple of 64; outputs [n][4] each */
+int  lpcn_debug_arith_identities(int device, const float *a, const float *b, uint32_t *out_mfma, uint32_t *out_mul,
+                                 uint32_t *out_pk, uint32_t *out_sc, size_t n);
 
 #ifdef __cplusplus
 }

@@ -166,7 +166,7 @@ template <int S> struct Lds {
     // ([block][48 rows] float4, 768 B per block) -- the chain then costs one read + four adds per block instead of two reads, two
     // packed multiplies and four adds.  Only S = 1 has the room (50 KB free of the 160 KB).
     static constexpr int PROD_BLOCKS = LPCN_PROD_BLOCKS, PROD_FIRST = 96 - PROD_BLOCKS;      // (the two assembly loops are generated for this split)
-    static constexpr int prod_sz = S == 1 ? PROD_BLOCKS * RB * 16 : 0;
+    static constexpr int prod_sz = S == 1 ? (PROD_BLOCKS + 7) * RB * 16 : 0;      // (+ 7 blocks: the chain wave's ring of eight reads ahead past the last block on its last trip)
     static constexpr int prod(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }
     static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? 0 : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state

@@ -201,3 +201,51 @@ def test_bench_eight_rank_shape_rehearsed_on_one_gpu(flag):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["parity_checked"] == 8 and "rehearsal" in d and d["config"]["sharding"].startswith("8 x 1024")
     assert d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from(hip_lib):
+    """the .so travels to the GPU box prebuilt; the source hashes baked into it (and echoed by bench.py) prove which
+    tree it was built from.  `dev` covers the device sources only, so a host-only change does not orphan the profiles."""
+    from lpcnet_amd import build
+    src, dev = build.source_hashes()
+    assert build.baked_hashes(api.LIB_PATH) == (src, dev)
+    assert api.build_info() == {"src": src, "dev": dev}
+    import bench
+    assert bench.kernel_source_hash() == dev
+    # a host-only edit moves `src` but not `dev`
+    import hashlib
+    host_only = [f for f in os.listdir(build.CSRC) if f.endswith(".c")]
+    assert sorted(host_only) == ["api.c", "model_pack.c"]
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(build.CSRC)):
+        if f.endswith((".h", ".hip", ".inc")):
+            h.update(f.encode() + open(os.path.join(build.CSRC, f), "rb").read())
+    flags = " ".join(x for x in build.HIP_FLAGS if not x.startswith("-I")) + " | "
+    h.update(flags.encode())
+    assert h.hexdigest()[:16] == dev
+
+
+def test_void_entry_points_do_not_abort_without_a_device_or_model(hip_lib, blob_f32, tmp_path):
+    """SURVEY 8b "Errors": lpcnet_synthesize & co. return void in the reference; on this engine a failing call zero-fills its output and
+    sets a sticky status instead of aborting the process (a child process: an abort would take the test run down)."""
+    code = (
+        "import sys, os, numpy as np; sys.path.insert(0, %r)\n"
+        "from lpcnet_amd import api\n"
+        "st = api.LPCNetState()\n"
+        "out = np.full(160, 77, np.int16)\n"
+        "api.load_library().lpcnet_synthesize(st.p, np.zeros(20, np.float32), out, 160)\n"
+        "assert not out.any() and api.status() < 0 and api.last_error(), (api.status(), api.last_error())\n"
+        "o2 = st.synthesize_tail_impl(40, np.arange(8, dtype=np.int16))\n"
+        "assert list(o2[:8]) == list(range(8)) and not o2[8:].any()\n"
+        "o3 = np.full(10, 5, np.int16)\n"
+        "api.load_library().lpcnet_synthesize_tail_impl(st.p, o3, 10, 11)\n"        # preload > N: refused, zero-filled, no abort
+        "assert not o3.any() and 'preload' in api.last_error()\n"
+        "first = api.status()\n"
+        "api.clear_error(); assert api.status() == 0 and api.last_error() == ''\n"
+        "print('ok', first)\n" % ROOT)
+    env = dict(os.environ, LPCNET_HIP_QUIET="1")
+    env.pop("LPCNET_HIP_MODEL", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok -"), (r.stdout[-300:], r.stderr[-1500:])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=dict(env, LPCNET_HIP_ABORT_ON_ERROR="1"))
+    assert r.returncode != 0 and "lpcnet_synthesize" in r.stderr            # the old stop-with-a-message, on request

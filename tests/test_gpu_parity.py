@@ -561,3 +561,95 @@ def test_tail_only_step_needs_a_frame_step_of_the_same_call(blob_f32, hip_lib):
     with pytest.raises(api.LPCNetError):
         b.synthesize_step(one, pcm, ns, pre, np.array([2, 0, 0], np.int32))
     b.close()
+
+
+def test_matrix_pipe_multiplier_and_packed_math_are_exact(hip_lib):
+    """PARITY's products come from v_mfma_f32_4x4x1 with C = -0.0 (S >= 2) and its sums / GRU-B products from v_pk_add_f32 /
+    v_pk_mul_f32: all three must be the vector unit's v_mul_f32 / v_add_f32 bit for bit, and v_mul_f32 must be IEEE binary32
+    multiplication -- over > 10^7 operand pairs stratified to subnormal inputs and products, underflow, +-0, the largest
+    finite products, overflow and infinities (src/vec.h:347-404: product, then add, separately rounded)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import arith_identities
+    rep = arith_identities.run(262144)
+    assert rep["total"]["products"] >= 10 ** 7
+    bad = {k: v for k, v in rep["strata"].items() if v["mfma_c_negzero_vs_v_mul_f32_mismatches"] or v["v_mul_f32_vs_ieee_host_mismatches"] or v["v_pk_mul_add_vs_scalar_mismatches"]}
+    assert not bad, bad
+    # the strata do reach the corners they are named after
+    assert rep["strata"]["subnormal state x normal weight in [1/128, 8)"]["results_subnormal"] > 10 ** 5
+    assert rep["strata"]["normal x normal, product in the subnormal range"]["results_subnormal"] > 10 ** 5
+    assert rep["strata"]["largest finite products and overflow"]["results_inf"] > 10 ** 5
+
+
+@pytest.mark.parametrize("S", [4, 2, 1])
+def test_gru_state_in_the_subnormal_range_end_to_end(blob_f32, S, hip_lib):
+    """A GRU state that has decayed into the subnormal range (reachable on silence): every GRU-A product of the next sample is
+    subnormal or underflows -- on the matrix pipe at S >= 2 -- and the engine must still follow the reference bit for bit."""
+    n, T = 4, 3
+    feats = feats_for(range(7300, 7300 + n), 2 * T)
+    rng = np.random.default_rng(11)
+    ga = (rng.uniform(0.2, 9.0, (n, 384)) * 1e-39 * rng.choice([-1.0, 1.0], (n, 384))).astype(np.float32)
+    gb = (rng.uniform(0.2, 9.0, (n, 16)) * 1e-39 * rng.choice([-1.0, 1.0], (n, 16))).astype(np.float32)
+    ga[:, ::7] = 0.0; ga[:, 3::11] = -0.0; ga[:, 5::13] = np.float32(1e-45)
+    assert (np.abs(ga[ga != 0]) < np.finfo(np.float32).tiny).all()
+    om = orc.OracleModel(blob_f32)
+    b = api.LPCNetBatch(n, blob_f32)
+    b.streams_per_workgroup = S
+    b.synthesize(np.ascontiguousarray(feats[:, :T]))              # past the start-up frames
+    want = np.zeros((n, T * 160), np.int16)
+    states = []
+    for s in range(n):
+        o = om.new_state()
+        o.synthesize(feats[s, :T])
+        o.L.orc_set_gru_state(o.p, np.ascontiguousarray(ga[s]), np.ascontiguousarray(gb[s]))
+        want[s] = o.synthesize(feats[s, T:])
+        states.append(o)
+        st = b.get_state(s)
+        st.gru_a[:] = ga[s].tolist(); st.gru_b[:] = gb[s].tolist()
+        assert np.array_equal(np.array(st.gru_a, np.float32).view(np.uint32), ga[s].view(np.uint32))      # (ctypes keeps subnormals and -0.0)
+        b.set_state(s, st)
+    got = b.synthesize(np.ascontiguousarray(feats[:, T:]))
+    assert np.array_equal(got, want)
+    for s in range(n):
+        st = b.get_state(s)
+        _, _, oa, ob = states[s].nnet_state()
+        assert np.array_equal(np.array(st.gru_a, np.float32).view(np.uint32), oa.view(np.uint32))
+        assert np.array_equal(np.array(st.gru_b, np.float32).view(np.uint32), ob.view(np.uint32))
+    b.close()
+
+
+def test_void_entry_points_fail_soft_with_a_sticky_status(blob_f32, hip_lib, monkeypatch):
+    """SURVEY §8b "Errors": a void entry point that cannot run zero-fills its output, leaves the state alone and records a sticky
+    per-thread status instead of aborting the process (here: a state with no model and no default model anywhere)."""
+    monkeypatch.chdir(os.path.dirname(os.path.abspath(__file__)))     # no ./weights_blob.bin here
+    monkeypatch.delenv("LPCNET_HIP_MODEL", raising=False)
+    monkeypatch.setenv("LPCNET_HIP_QUIET", "1")
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from lpcnet_amd import api\n"
+        "st = api.LPCNetState()\n"
+        "before = st.raw_bytes()\n"
+        "out = np.full(160, 77, np.int16)\n"
+        "api.load_library().lpcnet_synthesize(st.p, np.zeros(20, np.float32), out, 160)\n"
+        "assert not out.any(), 'output must be zero-filled'\n"
+        "assert api.status() == -5 and 'no model' in api.last_error(), (api.status(), api.last_error())\n"
+        "assert st.raw_bytes() == before\n"
+        "ga, gb, lpc = st.run_frame_network(np.zeros(20, np.float32))\n"
+        "assert not ga.any() and not lpc.any() and api.status() == -5\n"
+        "o2 = st.synthesize_tail_impl(40, np.arange(8, dtype=np.int16))\n"
+        "assert list(o2[:8]) == list(range(8)) and not o2[8:].any()\n"
+        "api.clear_error(); assert api.status() == 0 and api.last_error() == ''\n"
+        "print('soft-fail ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "soft-fail ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    # the old behaviour stays available for callers that prefer to stop
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, LPCNET_HIP_ABORT_ON_ERROR="1"))
+    assert r.returncode != 0 and "no model bound" in r.stderr
+    # a model that works keeps working afterwards, with a clean status
+    st = api.LPCNetState(blob_f32)
+    api.clear_error()
+    assert st.synthesize(feats_for([7400], 3)[0, 0]).shape == (160,) and api.status() == 0
+    assert hip_lib.lpcnet_hip_model_status(st.p, 0) == 0

@@ -392,3 +392,63 @@ def test_legacy_api_dispatcher_mixed_models_and_frame_lengths(hip_lib):
         t.join()
     for i in range(n):
         assert np.array_equal(got[i], want[i]), i
+
+
+_SMALLREG_CHILD = r"""
+import sys, threading, numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+from lpcnet_amd import api, synth
+feats = synth.make_features(1000, 6)
+run = lambda st, k=4: np.concatenate([st.synthesize(f) for f in feats[:k]])
+blobs = [synth.blob_bytes(synth.make_model(seed=3100 + i)) for i in range(7)]
+# ---- full-slot eviction: 4 slots; the 5th distinct blob evicts the least recently used one, whose stale handle is then DETECTED
+first = api.LPCNetState(blobs[0]); want0 = run(first)
+others = [api.LPCNetState(b) for b in blobs[1:4]]
+wants = [run(st) for st in others]                      # slots 1..3 used after slot 0
+fifth = api.LPCNetState(blobs[4])                       # table full: slot 0 (least recently used) goes
+assert np.any(run(fifth) != 0)
+out = np.full(160, 9, np.int16)
+api.clear_error()
+api.load_library().lpcnet_synthesize(first.p, np.ascontiguousarray(feats[0][:20]), out, 160)
+assert not out.any() and api.status() == -5 and "evicted" in api.last_error(), (api.status(), api.last_error())
+first.load_model(blobs[0]); first.reset(); api.clear_error()
+assert np.array_equal(run(first), want0) and api.status() == 0          # bound again: works, bit for bit
+# ---- device sides are recycled (2 resident) and slots evicted while other threads synthesize through the combining dispatcher
+errs, stop = [], threading.Event()
+def worker(blob, seed):
+    try:
+        st = api.LPCNetState(blob); ref = None
+        f = synth.make_features(seed, 3)
+        while not stop.is_set():
+            st.reset()
+            got = np.concatenate([st.synthesize(x) for x in f])
+            if api.status():                                # its model was evicted by the binder below: bind again, like a server would
+                api.clear_error(); st.load_model(blob); continue
+            if ref is None: ref = got
+            elif not np.array_equal(ref, got): errs.append(("mismatch", seed)); return
+    except Exception as e:
+        errs.append(repr(e))
+ths = [threading.Thread(target=worker, args=(blobs[i %% 2], 4000 + i)) for i in range(6)]
+for t in ths: t.start()
+for rnd in range(12):                                       # keep binding other models: device sides recycle, slots evict
+    st = api.LPCNetState(blobs[2 + rnd %% 5]); run(st, 1)
+stop.set()
+for t in ths: t.join()
+assert not errs, errs
+print("smallreg ok")
+"""
+
+
+def test_small_registry_eviction_and_recycling_under_load(hip_lib):
+    """the paths a 256-slot registry never reaches in a test -- a slot evicted altogether (stale handle detected: the call
+    fails soft with the 'evicted' message, binding again works) and device sides released / slots evicted while other threads are
+    inside the combining dispatcher -- on a library built with 4 slots / 2 resident device sides (lpcnet_amd/build.py)."""
+    import subprocess
+    import sys
+    from lpcnet_amd import build
+    lib = build.build_small_registry()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SMALLREG_CHILD % dict(root=root)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, LPCNET_HIP_LIB=lib, LPCNET_HIP_QUIET="1"))
+    assert r.returncode == 0 and "smallreg ok" in r.stdout, (r.stdout[-800:], r.stderr[-2500:])

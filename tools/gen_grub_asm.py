@@ -141,7 +141,8 @@ def main_lds(S):
     rdh = lambda slot, blk: f"ds_read_b128 v[{HR[slot]}:{HR[slot] + 3}], %[hp] offset:{ha_off(blk)}"
     prod = lambda pset, slot: [f"v_pk_mul_f32 v[{PS[pset]}:{PS[pset] + 1}], v[{HR[slot]}:{HR[slot] + 1}], v[{WR[slot]}:{WR[slot] + 1}]",
                                f"v_pk_mul_f32 v[{PS[pset] + 2}:{PS[pset] + 3}], v[{HR[slot] + 2}:{HR[slot] + 3}], v[{WR[slot] + 2}:{WR[slot] + 3}]"]
-    lines += [f"s_mov_b32 s{CNT}, {NBLK // BPT}"]
+    # (entry: nothing of the compiler's may be in flight under the partial waits below -- a scalar load returns out of order)
+    lines += ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{CNT}, {NBLK // BPT}"]
     if MASK48:          # only the 48 row lanes take part: a quarter less LDS return traffic per read
         lines += ["s_mov_b64 s[72:73], exec", "s_bfm_b64 exec, 48, 0"]
     for b in range(LA):
@@ -254,7 +255,7 @@ def main_prod(nblk):
     assert nblk % BPT == 0
     LA = R - 1
     rd = lambda slot, blk: f"ds_read_b128 v[{RG[slot]}:{RG[slot] + 3}], %[pp] offset:{blk * 768}"
-    lines = [f"s_mov_b32 s{CNT}, {nblk // BPT}"]
+    lines = ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{CNT}, {nblk // BPT}"]      # (entry: see --lds)
     for b in range(LA):
         lines += [rd(b % R, b)]
     lines += [f"s_waitcnt lgkmcnt({LA - 1})", ".p2align 4", "1:"]
@@ -262,7 +263,7 @@ def main_prod(nblk):
         a = [f"v_add_f32 %[z], %[z], v{RG[k % R] + j}" for j in range(4)]
         # the read of the block seven ahead issues in the shadow of the first dependent add; the wait for the NEXT block's
         # products sits behind the last add (LDS returns in order: at most LA - 1 younger reads may still be out)
-        lines += [a[0], rd((k + LA) % R, k + LA), a[1], a[2], a[3], f"s_waitcnt lgkmcnt({LA - 1})"]          # (reads past the end on the last trip: unused)
+        lines += [a[0], rd((k + LA) % R, k + LA), a[1], a[2], a[3], f"s_waitcnt lgkmcnt({LA - 1})"]          # (the last trip reads LA blocks past the end: Lds<1>::prod_sz pads for them)
     lines += [f"v_add_u32 %[pp], {BPT * 768}, %[pp]",
               f"s_sub_u32 s{CNT}, s{CNT}, 1",
               f"s_cmp_lg_u32 s{CNT}, 0",
