@@ -253,8 +253,9 @@ def rt_main(a, world, rank, local, dev):
         # device-side time of a step alone (HIP events on the kernels' stream), a few steps past the end
         batch.enable_timing(True)
         ks = []
+        d_scratch = torch.zeros((n, 160), dtype=torch.int16, device=dev)      # (not into d_pcm: the timed steps' output is checked below)
         for _ in range(3):
-            batch.synthesize_device(d_feat[T - 1].data_ptr(), 36, d_pcm[T - 1].data_ptr(), 1, stream)
+            batch.synthesize_device(d_feat[T - 1].data_ptr(), 36, d_scratch.data_ptr(), 1, stream)
             torch.cuda.synchronize()
             ks.append(batch.last_timing())
         batch.enable_timing(False)

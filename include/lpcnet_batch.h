@@ -134,6 +134,10 @@ LPCNET_EXPORT int lpcnet_hip_exp10_device(const float *x, double *out, int n);
  * inputs and products, underflow, +-0, the largest finite products, infinities). */
 LPCNET_EXPORT int lpcnet_hip_arith_identities_device(const float *a, const float *b, unsigned *out_mfma, unsigned *out_mul,
                                                      unsigned *out_pk, unsigned *out_sc, int n);
+/* The int8 kernels re-quantise the GRU states with ONE instruction (v_cvt_rpi_i32_f32) where the reference evaluates
+ * (int)floor(.5 + 127 x) with the sum in double (src/vec.h:311-316): this runs both over ALL 2^32 float bit patterns on the device.
+ * out3 = {mismatches among finite |t| < 2^31, mismatches inside the reachable |t| <= 127.5, one mismatching pattern}. */
+LPCNET_EXPORT int lpcnet_hip_quant_sweep_device(unsigned long long *out3);
 /* raw per-stream state record (layout = struct lpcn_stream_state in lpcnet_amd/csrc/lpcnet_engine.h) */
 LPCNET_EXPORT int lpcnet_batch_state_size(void);
 LPCNET_EXPORT int lpcnet_batch_get_raw_state(LPCNetBatch *b, int stream, void *out);

@@ -115,6 +115,7 @@ def load_library():
     L.lpcnet_batch_profile.argtypes = [vp, vp]
     _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
     L.lpcnet_hip_arith_identities_device.argtypes = [_f32p, _f32p, _u32p, _u32p, _u32p, _u32p, C.c_int]
+    L.lpcnet_hip_quant_sweep_device.argtypes = [C.POINTER(C.c_ulonglong)]
     L.lpcnet_hip_status.restype = C.c_int
     L.lpcnet_hip_clear_error.restype = None
     L.lpcnet_hip_model_status.argtypes = [vp, C.c_int]
@@ -147,6 +148,15 @@ def build_info() -> dict:
     """{'src': hash of every source the library was built from, 'dev': hash of the device sources alone}"""
     txt = load_library().lpcnet_hip_build_info().decode()
     return dict(kv.split("=", 1) for kv in txt.split())
+
+
+def quant_sweep():
+    """(mismatches over all finite |t| < 2^31, mismatches with |t| <= 127.5, a mismatching bit pattern) of v_cvt_rpi_i32_f32 vs floor(.5 + (double)t)"""
+    out = (C.c_ulonglong * 3)()
+    rc = load_library().lpcnet_hip_quant_sweep_device(out)
+    if rc:
+        raise LPCNetError(f"lpcnet_hip_quant_sweep_device failed ({rc}): " + last_error())
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def arith_identities(a: np.ndarray, b: np.ndarray):

@@ -69,12 +69,15 @@ def build(force=False, verbose=True, prof=False):
     (tools only; select it with LPCNET_HIP_LIB=<path>).  A library is up to date when the source hash it carries equals
     the tree's (not by file times: the .so travels to the GPU box prebuilt, and the hash is what proves it matches)."""
     lib = LIB.replace(".so", "_prof.so") if prof else LIB
+    suffix = os.environ.get("LPCN_LIB_SUFFIX", "")          # experiments: LPCN_EXTRA_FLAGS=-D... LPCN_LIB_SUFFIX=x -> liblpcnet_hip_x.so, objects in build_x/
+    if suffix:
+        lib = LIB.replace(".so", "_" + suffix + ".so")
     pf = ["-DLPCN_ENABLE_PROF=1"] + (["-DLPCN_PROF_MASK=" + os.environ["LPCN_PROF_MASK"]] if "LPCN_PROF_MASK" in os.environ else []) if prof else []
     extra = os.environ.get("LPCN_EXTRA_FLAGS", "").split()
     h_src, h_dev = source_hashes(pf + extra)
     if not force and baked_hashes(lib) == (h_src, h_dev):
         return lib
-    objdir = os.path.join(HERE, "build_prof" if prof else "build")
+    objdir = os.path.join(HERE, "build_" + suffix if suffix else ("build_prof" if prof else "build"))
     os.makedirs(objdir, exist_ok=True)
     objs = []
 

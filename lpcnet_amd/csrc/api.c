@@ -1266,6 +1266,13 @@ int lpcnet_hip_arith_identities_device(const float *a, const float *b, unsigned 
     FWD(lpcn_debug_arith_identities(single_stream_device(), a, b, out_mfma, out_mul, out_pk, out_sc, (size_t)n));
 }
 
+/* test seam (include/lpcnet_batch.h): the int8 kernels' one-instruction re-quantisation against the reference's formula, exhaustively */
+int lpcnet_hip_quant_sweep_device(unsigned long long *out3)
+{
+    if (!out3) { set_err("lpcnet_hip_quant_sweep_device: bad arguments"); return LPCN_E_ARG; }
+    FWD(lpcn_debug_quant_sweep(single_stream_device(), out3));
+}
+
 /* Host-only model check (no GPU needed): parses the blob with the loader's rules, builds the device
  * packings and verifies them.  info[0..5] = {is_int8, blocks GRU-A, blocks GRU-B, items per lane,
  * padded GRU-B blocks, selftest code}.  Returns 0 if the blob is loadable by the engine (float or

@@ -1052,13 +1052,15 @@ __global__ void lpcn_arith_identity_kernel(const float *a, const float *b, uint3
     asm volatile("" : "+v"(negz));                         // (the same guard as the kernel's: the addend must reach the instruction as -0.0)
     const float av = a[i], bv = b[i];
     const f4 p = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, negz, 0, 0, 0);
+    // (element-wise copies first: hipcc's __builtin_bit_cast of an ext-vector ELEMENT reads element 0 whatever the index)
+    const float pe[4] = {p[0], p[1], p[2], p[3]};
     const size_t q = i & ~(size_t)3;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float ak = a[q + k], m;
         asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m) : "v"(ak), "v"(bv));
-        out_mfma[i * 4 + k] = __builtin_bit_cast(uint32_t, p[k]);
-        out_mul[i * 4 + k] = __builtin_bit_cast(uint32_t, m);
+        out_mfma[i * 4 + k] = __float_as_uint(pe[k]);
+        out_mul[i * 4 + k] = __float_as_uint(m);
     }
     const float a2 = a[i ^ 1], b2 = b[i ^ 1];
     f2 x = {av, a2}, y = {bv, b2}, pm, pa;
@@ -1069,10 +1071,11 @@ __global__ void lpcn_arith_identity_kernel(const float *a, const float *b, uint3
     asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1) : "v"(a2), "v"(b2));
     asm volatile("v_add_f32 %0, %1, %2" : "=v"(s0) : "v"(av), "v"(bv));
     asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(a2), "v"(b2));
-    out_pk[i * 4 + 0] = __builtin_bit_cast(uint32_t, pm[0]); out_pk[i * 4 + 1] = __builtin_bit_cast(uint32_t, pm[1]);
-    out_pk[i * 4 + 2] = __builtin_bit_cast(uint32_t, pa[0]); out_pk[i * 4 + 3] = __builtin_bit_cast(uint32_t, pa[1]);
-    out_sc[i * 4 + 0] = __builtin_bit_cast(uint32_t, m0); out_sc[i * 4 + 1] = __builtin_bit_cast(uint32_t, m1);
-    out_sc[i * 4 + 2] = __builtin_bit_cast(uint32_t, s0); out_sc[i * 4 + 3] = __builtin_bit_cast(uint32_t, s1);
+    const float pk0 = pm[0], pk1 = pm[1], pk2 = pa[0], pk3 = pa[1];
+    out_pk[i * 4 + 0] = __float_as_uint(pk0); out_pk[i * 4 + 1] = __float_as_uint(pk1);
+    out_pk[i * 4 + 2] = __float_as_uint(pk2); out_pk[i * 4 + 3] = __float_as_uint(pk3);
+    out_sc[i * 4 + 0] = __float_as_uint(m0); out_sc[i * 4 + 1] = __float_as_uint(m1);
+    out_sc[i * 4 + 2] = __float_as_uint(s0); out_sc[i * 4 + 3] = __float_as_uint(s1);
 }
 
 extern "C" int lpcn_debug_arith_identities(int device, const float *a, const float *b, uint32_t *out_mfma, uint32_t *out_mul,
@@ -1099,5 +1102,45 @@ extern "C" int lpcn_debug_arith_identities(int device, const float *a, const flo
     }
     (void)hipFree(d_in); (void)hipFree(d_out);
     if (rc) snprintf(g_err, sizeof(g_err), "arithmetic identity test kernel failed");
+    return rc;
+}
+
+// test seam: the state re-quantisation of the int8 kernels.  The reference computes (int)floor(.5 + t) with t = 127 x rounded to float and the
+// sum in DOUBLE (src/vec.h:311-316: exact, 0.5 + t needs at most 31 bits); the kernels use ONE instruction, v_cvt_rpi_i32_f32 ("round to
+// nearest, ties toward +infinity" = floor(t + 0.5) evaluated exactly), when LPCN_QUANT_RPI is set.  This sweep compares both on ALL 2^32 bit
+// patterns: out[0] = mismatches among the finite t with |t| < 2^31, out[1] = mismatches inside the reachable range |t| <= 127.5 (|x| <= 1),
+// out[2] = one mismatching bit pattern (if any).
+__global__ void lpcn_quant_sweep_kernel(unsigned long long *out)
+{
+    const uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) * 256u;
+    unsigned bad = 0, bad_in = 0;
+    for (uint32_t k = 0; k < 256u; ++k) {
+        const uint32_t u = base + k;
+        const float t = __uint_as_float(u);
+        if (!(fabsf(t) < 2147483648.f)) continue;            // NaN, infinities and |t| >= 2^31: the C conversion is undefined there
+        const int want = (int)floor(.5 + (double)t);
+        int got;
+        asm volatile("v_cvt_rpi_i32_f32 %0, %1" : "=v"(got) : "v"(t));
+        if (got != want) { ++bad; if (fabsf(t) <= 127.5f) ++bad_in; out[2] = u; }
+    }
+    if (bad) atomicAdd(&out[0], (unsigned long long)bad);
+    if (bad_in) atomicAdd(&out[1], (unsigned long long)bad_in);
+}
+
+extern "C" int lpcn_debug_quant_sweep(int device, unsigned long long *out3)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { snprintf(g_err, sizeof(g_err), "no such HIP device"); return LPCN_E_NODEVICE; }
+    DeviceGuard guard(device);
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 3 * sizeof(unsigned long long)));
+    int rc = 0;
+    if (hipMemset(d, 0, 3 * sizeof(unsigned long long)) != hipSuccess) rc = LPCN_E_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(lpcn_quant_sweep_kernel, dim3(65536), dim3(256), 0, 0, d);      // 2^16 x 2^8 threads x 2^8 patterns
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out3, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = LPCN_E_HIP;
+    }
+    (void)hipFree(d);
+    if (rc) snprintf(g_err, sizeof(g_err), "quantisation sweep kernel failed");
     return rc;
 }

@@ -159,19 +159,138 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel F2: cond[128] -> GRU-A conditioning (1152, bias included) and GRU-B conditioning (48)
-// (src/lpcnet.c:105-106).  Workgroup = (stream, tile of FT frames), lane = output column.
+// Kernel F1', n_frames == 1 (the real-time operating point: one 10-ms frame per stream and step, src/lpcnet_demo.c:203-219, and every
+// pass of the legacy API's combining dispatcher): the tile runs over ST STREAMS instead of FT frames of one stream, so a weight
+// load still feeds ST accumulators.  F1 with one frame per stream reads the 453 KB of conv / dense weights once per stream and
+// throws 7 of its 8 accumulators away: 0.81 ms for 8 192 streams (8 % of the 10-ms step), L2-bandwidth bound.  Same arithmetic per
+// output (inputs in ascending order, multiply and add rounded separately): bit-identical to F1.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void frame_proj_kernel(LpcnFrameModel M, int n_frames, int tiles_per_stream, const float *cond,
+constexpr int ST = 8;            // streams per tile
+
+__global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, int n_streams, const float *feat, size_t feat_stream_stride,
+                                                            lpcn_stream_state *states, int *fc_base, float *cond_out /*[stream][128]*/,
+                                                            float *lpc_out /*[stream][16]*/)
+{
+    __shared__ float x1[ST][3 * FIN];         // per stream: conv1 window = 2 history frames + the new frame
+    __shared__ float x2[ST][3 * CN];          // conv2 window
+    __shared__ float y[ST][CN];
+    __shared__ float tansig[204];
+    __shared__ int fcs[ST];
+    const int i = threadIdx.x;
+    const int s0 = blockIdx.x * ST;
+    const int ns = n_streams - s0 < ST ? n_streams - s0 : ST;
+    for (int k = i; k < 201; k += 128) tansig[k] = M.tab_tansig[k];
+    for (int k = i; k < ST * 2 * FIN; k += 128) {
+        const int t = k / (2 * FIN), c = k % (2 * FIN);
+        x1[t][c] = t < ns ? states[s0 + t].conv1_mem[c] : 0.f;
+    }
+    for (int k = i; k < ST * 2 * CN; k += 128) {
+        const int t = k / (2 * CN), c = k % (2 * CN);
+        x2[t][c] = t < ns ? states[s0 + t].conv2_mem[c] : 0.f;
+    }
+    // inputs: 20 features + 64-d pitch embedding (src/lpcnet.c:93-97)
+    for (int k = i; k < ST * FIN; k += 128) {
+        const int t = k / FIN, c = k % FIN;
+        float v = 0.f;
+        if (t < ns) {
+            const float *ft = feat + (size_t)(s0 + t) * feat_stream_stride;
+            if (c < LPCN_NB_FEAT) v = ft[c];
+            else {
+                int pitch = (int)floor(.1 + (double)(50.f * ft[LPCN_NB_BANDS]) + 100);
+                pitch = pitch < 33 ? 33 : (pitch > 255 ? 255 : pitch);
+                v = M.pitch_emb[pitch * LPCN_PITCH_EMB + (c - LPCN_NB_FEAT)];
+            }
+        }
+        x1[t][2 * FIN + c] = v;
+    }
+    if (i < ST) fcs[i] = i < ns ? states[s0 + i].frame_count : 0;
+    // LPC delay line with a single frame: the frame uses the coefficients of two frames ago, the line shifts (src/lpcnet.c:110-111)
+    if (!M.end2end) {
+        for (int k = i; k < ns * LPCN_LPC_ORDER; k += 128) {
+            const int t = k / LPCN_LPC_ORDER, c = k % LPCN_LPC_ORDER;
+            lpcn_stream_state *st = &states[s0 + t];
+            float g = M.lpc_gamma, gi = g;
+            for (int q = 0; q < c; ++q) gi *= g;
+            lpc_out[(size_t)(s0 + t) * LPCN_LPC_ORDER + c] = st->old_lpc[1][c] * gi;
+            st->old_lpc[1][c] = st->old_lpc[0][c];
+        }
+    }
+    __syncthreads();
+    float acc[ST];
+#pragma unroll
+    for (int t = 0; t < ST; ++t) acc[t] = M.conv1_b[i];
+    for (int j = 0; j < 3 * FIN; ++j) {
+        const float wv = M.conv1_w[j * CN + i];
+#pragma unroll
+        for (int t = 0; t < ST; ++t) acc[t] = acc[t] + wv * x1[t][j];
+    }
+#pragma unroll
+    for (int t = 0; t < ST; ++t) {
+        float v = lpcn_tanh(acc[t], tansig);
+        if (fcs[t] < 1) v = 0.f;                                      // src/lpcnet.c:99
+        x2[t][2 * CN + i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < ST; ++t) acc[t] = M.conv2_b[i];
+    for (int j = 0; j < 3 * CN; ++j) {
+        const float wv = M.conv2_w[j * CN + i];
+#pragma unroll
+        for (int t = 0; t < ST; ++t) acc[t] = acc[t] + wv * x2[t][j];
+    }
+#pragma unroll
+    for (int t = 0; t < ST; ++t) {
+        float v = lpcn_tanh(acc[t], tansig);
+        if (fcs[t] < LPCN_FEATURES_DELAY) v = 0.f;                    // src/lpcnet.c:101
+        y[t][i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < ST; ++t) acc[t] = M.dense1_b[i];
+    for (int j = 0; j < CN; ++j) {
+        const float wv = M.dense1_w[j * CN + i];
+#pragma unroll
+        for (int t = 0; t < ST; ++t) acc[t] = acc[t] + wv * y[t][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < ST; ++t) y[t][i] = lpcn_tanh(acc[t], tansig);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < ST; ++t) acc[t] = M.dense2_b[i];
+    for (int j = 0; j < CN; ++j) {
+        const float wv = M.dense2_w[j * CN + i];
+#pragma unroll
+        for (int t = 0; t < ST; ++t) acc[t] = acc[t] + wv * y[t][j];
+    }
+#pragma unroll
+    for (int t = 0; t < ST; ++t)
+        if (t < ns) cond_out[(size_t)(s0 + t) * CN + i] = lpcn_tanh(acc[t], tansig);
+    // histories: the last two frames of the window (src/nnet.c:469); frame_count (src/lpcnet.c:119)
+    for (int k = i; k < ns * 2 * FIN; k += 128) states[s0 + k / (2 * FIN)].conv1_mem[k % (2 * FIN)] = x1[k / (2 * FIN)][FIN + k % (2 * FIN)];
+    for (int k = i; k < ns * 2 * CN; k += 128) states[s0 + k / (2 * CN)].conv2_mem[k % (2 * CN)] = x2[k / (2 * CN)][CN + k % (2 * CN)];
+    if (i < ns) {
+        fc_base[s0 + i] = fcs[i];
+        states[s0 + i].frame_count = fcs[i] + 1 > 1000 ? 1000 : fcs[i] + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel F2: cond[128] -> GRU-A conditioning (1152, bias included) and GRU-B conditioning (48)
+// (src/lpcnet.c:105-106).  Workgroup = tile of FT consecutive (stream, frame) items of the flattened [stream][frame] index -- all
+// three arrays are dense in it -- so a tile is full whatever the number of frames per stream (round 5: with one frame per stream,
+// the real-time case, a tile per stream used one accumulator of eight).  Lane = output column.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void frame_proj_kernel(LpcnFrameModel M, size_t n_items, const float *cond,
                                                          float *cond_a, float *cond_b)
 {
     __shared__ float c[FT * CN];
     const int i = threadIdx.x;
-    const int stream = blockIdx.x / tiles_per_stream, t0 = (blockIdx.x % tiles_per_stream) * FT;
-    const int nt = n_frames - t0 < FT ? n_frames - t0 : FT;
+    const size_t item0 = (size_t)blockIdx.x * FT;
+    const int nt = n_items - item0 < (size_t)FT ? (int)(n_items - item0) : FT;
     for (int k = i; k < FT * CN; k += 128) {
         const int t = k / CN;
-        c[k] = t < nt ? cond[((size_t)stream * n_frames + t0 + t) * CN + k % CN] : 0.f;
+        c[k] = t < nt ? cond[(item0 + t) * CN + k % CN] : 0.f;
     }
     __syncthreads();
     float acc[FT];
@@ -186,7 +305,7 @@ __global__ __launch_bounds__(128) void frame_proj_kernel(LpcnFrameModel M, int n
         }
 #pragma unroll
         for (int t = 0; t < FT; ++t)
-            if (t < nt) cond_a[((size_t)stream * n_frames + t0 + t) * LPCN_ROWS_A + r] = acc[t];
+            if (t < nt) cond_a[(item0 + t) * LPCN_ROWS_A + r] = acc[t];
     }
     if (i < LPCN_ROWS_B) {
 #pragma unroll
@@ -198,7 +317,7 @@ __global__ __launch_bounds__(128) void frame_proj_kernel(LpcnFrameModel M, int n
         }
 #pragma unroll
         for (int t = 0; t < FT; ++t)
-            if (t < nt) cond_b[((size_t)stream * n_frames + t0 + t) * LPCN_ROWS_B + i] = acc[t];
+            if (t < nt) cond_b[(item0 + t) * LPCN_ROWS_B + i] = acc[t];
     }
 }
 
@@ -395,11 +514,14 @@ static inline int lpcn_launch_frame_kernels(const LpcnFrameModel &M, hipStream_t
                                             int feat_stride, size_t feat_stream_stride, lpcn_stream_state *d_state, int *d_fc_base,
                                             float *d_cond, float *d_cond_a, float *d_cond_b, float *d_lpc, char *err, size_t errlen)
 {
-    hipLaunchKernelGGL(lpcn::frame_cond_kernel, dim3(n), dim3(128), 0, st, M, n_frames, d_feat, feat_stride, feat_stream_stride,
-                       d_state, d_fc_base, d_cond, d_lpc);
-    const int tiles = (n_frames + lpcn::FT - 1) / lpcn::FT;
-    hipLaunchKernelGGL(lpcn::frame_proj_kernel, dim3(n * tiles), dim3(128), 0, st, M, n_frames, tiles, (const float *)d_cond, d_cond_a, d_cond_b);
     const size_t items = (size_t)n * n_frames;
+    if (n_frames == 1)       // one frame per stream (real-time steps, the legacy API's passes): tiles of ST streams
+        hipLaunchKernelGGL(lpcn::frame_cond_t1_kernel, dim3((n + lpcn::ST - 1) / lpcn::ST), dim3(128), 0, st, M, n, d_feat, feat_stream_stride,
+                           d_state, d_fc_base, d_cond, d_lpc);
+    else
+        hipLaunchKernelGGL(lpcn::frame_cond_kernel, dim3(n), dim3(128), 0, st, M, n_frames, d_feat, feat_stride, feat_stream_stride,
+                           d_state, d_fc_base, d_cond, d_lpc);
+    hipLaunchKernelGGL(lpcn::frame_proj_kernel, dim3((unsigned)((items + lpcn::FT - 1) / lpcn::FT)), dim3(128), 0, st, M, items, (const float *)d_cond, d_cond_a, d_cond_b);
     if (M.end2end)
         hipLaunchKernelGGL(lpcn::rc2lpc_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, M, (int)items, (const float *)d_cond, d_lpc);
     else

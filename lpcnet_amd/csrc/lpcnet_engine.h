@@ -192,6 +192,9 @@ int  lpcn_batch_dev_profile(lpcn_batch_dev *b, unsigned long long *out);
 int  lpcn_debug_exp10(int device, const float *x, double *out, size_t n);
 /* test seam: v_mfma_f32_4x4x1 with C = -0.0 against v_mul_f32, and the halves of v_pk_mul_f32 / v_pk_add_f32 against the scalar
  * instructions, as bit patterns (engine.hip: lpcn_arith_identity_kernel); n = operand count, a multiple of 64; outputs [n][4] each */
+/* test seam: v_cvt_rpi_i32_f32 against (int)floor(.5 + (double)t) on all 2^32 bit patterns (engine.hip: lpcn_quant_sweep_kernel);
+ * out3 = {mismatches among finite |t| < 2^31, mismatches with |t| <= 127.5, one mismatching pattern} */
+int  lpcn_debug_quant_sweep(int device, unsigned long long *out3);
 int  lpcn_debug_arith_identities(int device, const float *a, const float *b, uint32_t *out_mfma, uint32_t *out_mul,
                                  uint32_t *out_pk, uint32_t *out_sc, size_t n);
 

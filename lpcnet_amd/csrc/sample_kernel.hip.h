@@ -199,10 +199,20 @@ template <int SEL> __device__ __forceinline__ float fmac_quad(float acc, const f
 //   x_q = (signed char)(int)floor(.5 + 127*x)   (float product, double sum)
 //   out = out*(128*127);  out += (w0*x0 + w1*x1 + w2*x2 + w3*x3) per block (exact integer);  out *= 1/128/127
 constexpr float QS = 128.f * 127.f, QS1 = 1.f / 128.f / 127.f;
+#ifndef LPCN_QUANT_RPI
+#define LPCN_QUANT_RPI 1        // 1: floor(.5 + t) as ONE instruction, v_cvt_rpi_i32_f32 (round to nearest, ties toward +infinity), instead of four in double (round 5: 157.5 vs 156.8 M int8)
+#endif
 __device__ __forceinline__ int quant_s8(float x)
 {
     const float t = 127.f * x;
+#if LPCN_QUANT_RPI
+    // == (int)floor(.5 + (double)t) for every finite t (lpcnet_hip_quant_sweep_device: all 2^32 bit patterns on the device)
+    int q;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(t));
+    return q & 0xFF;
+#else
     return (int)floor(.5 + (double)t) & 0xFF;
+#endif
 }
 // Integer dot products converted to float.  v_dot4_i32_i8 with a literal-zero accumulator saves the
 // v_mov the compiler's v_dot4c selection needs, but the hazard recogniser cannot see inside inline
@@ -1130,10 +1140,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // One work item per (neuron, stream): update/reset sigmoids, candidate tanh and the blend
             // (src/nnet.c:441-447).  sm_pre / sm_inh / sm_hT are [row][stream], so item i = n*S + s is
             // simply element i of each gate's third: consecutive lanes touch consecutive words.
-            {
+            // S = 2: 768 items on 512 lanes -- the second round is empty for waves 4..7; S = 1: 384 items -- waves 6, 7 have none.  A wave
+            // runs only the rounds in which it has items (wave-uniform count, one scalar branch): the instructions of an empty round
+            // are issue slots taken from the waves that share the SIMD (two workgroups per CU for the int8 kernels).
+            auto gate_stage = [&](auto nqc) __attribute__((always_inline)) {
                 constexpr int NI = NA * S;                                     // items
-                constexpr int NQ = (NI + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
+                constexpr int NQ = decltype(nqc)::value;                       // rounds of this wave
                 constexpr bool FULL = NI % LPCN_WG_THREADS == 0;               // (S = 4: every lane has an item in every round -- no range tests, no selects)
+                if constexpr (NQ > 0) {
                 float z[NQ], rg[NQ], a[NQ], hold[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -1172,6 +1186,22 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                             }
                         }
                     }
+                }
+                }
+            };
+            {
+                constexpr int NI = NA * S, NQ_MAX = (NI + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
+#ifndef LPCN_GATE_ROUNDS
+#define LPCN_GATE_ROUNDS 0      // 1: a wave skips the gate-stage rounds in which it has no item (S = 1, 2); 0: every wave runs every round.  Measured in round 5 (int8,
+                                // S = 2 x 2 workgroups per CU: 138 -> 69 VALU instructions on waves 4..7): 156.8 vs 157.9 M samples/s -- SLOWER; fp32 at 512 streams 74.8 vs 74.8.
+                                // The empty round's instructions are not what the phase waits for, and the wave-divergent paths cost more at the barrier than they save.
+#endif
+                if constexpr (NI % LPCN_WG_THREADS == 0 || !LPCN_GATE_ROUNDS) gate_stage(std::integral_constant<int, NQ_MAX>{});
+                else {
+                    // this wave's lanes are tid0 = 64 w .. 64 w + 63: round q holds items for it iff q * 512 + 64 w < NI
+                    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                    if ((NQ_MAX - 1) * LPCN_WG_THREADS + wv * 64 < NI) gate_stage(std::integral_constant<int, NQ_MAX>{});
+                    else gate_stage(std::integral_constant<int, NQ_MAX - 1>{});
                 }
             }
             __syncthreads();                                                   // B2

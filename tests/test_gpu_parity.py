@@ -653,3 +653,12 @@ def test_void_entry_points_fail_soft_with_a_sticky_status(blob_f32, hip_lib, mon
     api.clear_error()
     assert st.synthesize(feats_for([7400], 3)[0, 0]).shape == (160,) and api.status() == 0
     assert hip_lib.lpcnet_hip_model_status(st.p, 0) == 0
+
+
+def test_int8_requantisation_instruction_is_the_reference_formula_on_every_float(hip_lib):
+    """src/vec.h:311-316 quantises the GRU states as (int)floor(.5 + 127 x) with the sum in double; the int8 kernels may use ONE instruction,
+    v_cvt_rpi_i32_f32 (LPCN_QUANT_RPI).  The device compares both on all 2^32 float bit patterns: not one may differ where the C
+    expression is defined (finite, |t| < 2^31), in particular none inside the reachable range |t| <= 127.5."""
+    bad_all, bad_reachable, pattern = api.quant_sweep()
+    assert bad_reachable == 0, (bad_reachable, hex(pattern))
+    print("v_cvt_rpi_i32_f32 vs floor(.5 + (double)t): mismatches over all finite |t| < 2^31:", bad_all, hex(pattern))

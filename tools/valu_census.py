@@ -25,10 +25,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def compile_asm(path):
+def compile_asm(path, int8=False):
     from lpcnet_amd import build
-    cmd = [build.HIPCC] + build.HIP_FLAGS + ["-DLPCN_S=4", "-DLPCN_ONLY_BENCH_VARIANT=1", "--cuda-device-only", "-S",
-                                             os.path.join(build.CSRC, "sample_variants.hip"), "-o", path]
+    sel = ["-DLPCN_S=2", "-DLPCN_ONLY_BENCH_VARIANT=2"] if int8 else ["-DLPCN_S=4", "-DLPCN_ONLY_BENCH_VARIANT=1"]
+    cmd = [build.HIPCC] + build.HIP_FLAGS + sel + ["--cuda-device-only", "-S", os.path.join(build.CSRC, "sample_variants.hip"), "-o", path]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
 
 
@@ -73,10 +73,10 @@ def items_of(lines):
     return item_cost, rest
 
 
-def layout():
+def layout(int8=False):
     from lpcnet_amd import api, synth
     L = api.load_library()
-    blob = synth.blob_bytes(synth.make_model())
+    blob = synth.blob_bytes(synth.make_model(flavour="int8" if int8 else "float"))
     out = (C.c_int * 65)()
     L.lpcnet_hip_model_layout.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     assert L.lpcnet_hip_model_layout(blob, len(blob), out) == 0
@@ -89,11 +89,126 @@ def layout():
     return waves
 
 
+def loop_regions(lines, head, end):
+    """the sample loop cut at its workgroup barriers: [P1, P2, P3, P4, P5] as line lists"""
+    bars = [i for i, ln in enumerate(lines[:end]) if ln.strip() == "s_barrier" and i > head]
+    b1, b2, b3, b4 = bars[-4:]
+    return dict(P1=lines[head:b1], P2=lines[b1:b2], P3=lines[b2:b3], P4=lines[b3:b4], P5=lines[b4:end])
+
+
+def find_loop(lines):
+    end = next(i for i, ln in enumerate(lines) if "LPCN_SAMPLE_LOOP_END" in ln)
+    for ln in lines[end:end + 80]:                          # the first branch behind the marker that goes BACKWARD is the loop's back edge
+        m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+        if m:
+            tgt = next((i for i, l2 in enumerate(lines) if l2.startswith(m.group(1) + ":")), None)
+            if tgt is not None and tgt < end:
+                return tgt, end
+    raise SystemExit("sample loop not found")
+
+
+def split_at_mfma(lines, opcode):
+    """int8 items: the chain is cut at every matrix-pipe instruction; a segment = [mfma, next mfma) holds the tail of one item (wait states,
+    2 conversions, packed add) and the front of the next (offset unpack, state fetch, exit test).  Returns (segments' counts, lines outside)."""
+    idx = [i for i, ln in enumerate(lines) if ln.strip().startswith(opcode)]
+    segs = [count(lines[a:b]) for a, b in zip(idx, idx[1:])]
+    return idx, segs
+
+
+def inner_loops(lines):
+    """(start, end) line ranges of the loops INSIDE a region: a label followed later by a conditional branch back to it"""
+    labels = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", ln)] if m}
+    out = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"\s+s_cbranch\w*\s+(\.LBB\d+_\d+)", ln)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            out.append((labels[m.group(1)], i + 1))
+    return out
+
+
+def main_int8(a):
+    """sample_kernel<2, 32, true, false, true>: int8 blobs, PARITY, two workgroups per CU."""
+    path = a.asm
+    if not path:
+        path = os.path.join(tempfile.mkdtemp(prefix="lpcn_census_"), "k.s")
+        compile_asm(path, int8=True)
+    text = open(path).read()
+    m = re.search(r"^(_ZN4lpcn13sample_kernelILi2ELi32ELb1ELb0ELb1EEE\w+):", text, re.M)
+    lines = text[m.start():].split("\n") if m else text.split("\n")
+    lines = lines[:next(i for i, ln in enumerate(lines) if ".end_amdhsa_kernel" in ln)]
+    head, end = find_loop(lines)
+    R = loop_regions(lines, head, end)
+    waves = layout(int8=True)
+    S = 2
+    rows, tot = [], dict(valu=0, mfma=0, lds=0)
+
+    def add(phase, what, per, units, note):
+        rows.append((phase, what, per["valu"], per["mfma"], per["lds"], per["salu"], units, round(per["valu"] * units), round(per["mfma"] * units), note))
+        tot["valu"] += per["valu"] * units; tot["mfma"] += per["mfma"] * units; tot["lds"] += per["lds"] * units
+
+    med = lambda xs, k: sorted(x[k] for x in xs)[len(xs) // 2]
+    zero = dict(valu=0, mfma=0, lds=0, vmem=0, salu=0, pk=0, dpp=0)
+    sub = lambda c, d, n: {k: c[k] - d[k] * n for k in c}
+    # ---- P1
+    idx1, seg1 = split_at_mfma(R["P1"], "v_mfma_i32")
+    item = {k: med(seg1, k) for k in seg1[0]}
+    item["mfma"] = 1
+    n1 = sum(w["p1_items"] for w in waves)
+    add("P1", "GRU-A item: 1 v_mfma_i32_4x4x4i8 (the item's block products of both streams), 2 conversions, 1 packed add, offset unpack (2), state fetch, exit test",
+        item, n1, f"{n1} wave-items per step outside the heads ({'; '.join(str(w['p1_items']) for w in waves)} per wave)")
+    c1 = count(R["P1"])
+    rest1 = sub(c1, item, len(idx1))
+    half = {k: max(v, 0) / 2 for k, v in rest1.items()}
+    add("P1", "start values (3 slots x 2 streams: bias + diag*h, x 128*127), gather issue + 9 gather adds per stream and slot, slot boundaries, close (static count / 2: a wave runs one of the two start paths)",
+        half, 8, f"static: {rest1['valu']} VALU, {rest1['lds']} LDS, {rest1['vmem']} VMEM outside the {len(idx1)} item bodies")
+    # ---- P2
+    c2 = count(R["P2"])
+    add("P2", "gate stage: 768 (neuron, stream) items on 512 lanes = 2 rounds (the second half empty), 2 sigmoid + 1 tanh (table) each, blend, re-quantisation floor(.5 + 127 x) in double, byte stores", c2, 8, "straight-line")
+    # ---- P3: GRU-B's quad loop on waves 0..1, heads on waves 3..7, the rest
+    loops = [(s0, e0) for s0, e0 in inner_loops(R["P3"]) if any("v_dot4" in ln for ln in R["P3"][s0:e0])]
+    gb = zero
+    gb_lines = set()
+    if loops:
+        s0, e0 = max(loops, key=lambda t: t[1] - t[0])
+        body = count(R["P3"][s0:e0])
+        nq = sum(1 for ln in R["P3"][s0:e0] if ln.strip().startswith("v_dot4")) // 4
+        gb = {k: v / nq for k, v in body.items()}
+        gb_lines = set(range(s0, e0))
+        add("P3", "GRU-B quad of 4 input blocks: 4 v_dot4_i32_i8 + 4 conversions + 4 dependent adds + 2 LDS reads (compiler's loop, two quads per trip)", gb, 24 * S,
+            f"24 quads x {S} streams; loop body of {nq} quads: {body['valu']} VALU")
+    p3 = [ln for i, ln in enumerate(R["P3"]) if i not in gb_lines]
+    idx3, seg3 = split_at_mfma(p3, "v_mfma_i32")
+    n_head = sum(w["head"] for w in waves)
+    it3 = {k: med(seg3, k) for k in seg3[0]} if seg3 else item
+    it3["mfma"] = 1
+    add("P3", "candidate HEAD item (same body as P1's)", it3, n_head, f"{n_head} wave-items per step ({'; '.join(str(w['head']) for w in waves)} per wave)")
+    rest3 = sub(count(p3), it3, len(idx3))
+    add("P3", "recurrent part + GRU-B gates + re-quantisation (gate waves 0, 1), head start values (waves 3..7), dual-FC row prefetch (all) (static count / 2: gate and head waves run different halves)",
+        {k: max(v, 0) / 2 for k, v in rest3.items()}, 8, f"static: {rest3['valu']} VALU outside the {len(idx3)} head item bodies and the quad loop")
+    add("P4", "tree: 255 nodes x 2 channels x 2 streams speculatively (16 mul + 16 add + table tanh per stream and lane), ballots", count(R["P4"]), 8, "straight-line")
+    add("P5", "leader (wave 0): tree walk, mu-law, LPC chain, publish; thresholds (wave 1)", count(R["P5"]), 1, "straight-line, one wave")
+    hdr = "phase,what,VALU_per_unit,MFMA_per_unit,LDS_per_unit,SALU_per_unit,units_per_step,VALU_wave_insts_per_step,MFMA_wave_insts_per_step,note"
+    out = [hdr] + [",".join(str(x).replace(",", ";") for x in r) for r in rows]
+    lane_ops = tot["valu"] * 64 / S
+    gemv = (n1 + n_head) * (item["valu"] - 2) + 24 * S * gb.get("valu", 0)
+    out.append(f"TOTAL,,,,,,,{round(tot['valu'])},{round(tot['mfma'])},\"= {lane_ops / 1000:.0f} k VALU lane-operations per stream-sample ({S} streams per workgroup; + {tot['mfma'] * 64 / S / 1000:.0f} k lanes x matrix-pipe instructions); "
+               f"of which the two mat-vecs (items without their address arithmetic + GRU-B quads): {gemv * 64 / S / 1000:.0f} k; measured SQ_INSTS_VALU x 64 / samples = 192 k (profiles/r04_sq_counters_int8.csv)\"")
+    txt = "\n".join(out)
+    print(txt)
+    if a.csv:
+        with open(a.csv, "w") as f:
+            f.write("# tools/valu_census.py --int8: per-phase instruction census of sample_kernel<2,32,true,false,true> (int8 blobs, PARITY, two workgroups per CU) from the compiler's assembly; wave-instructions per sample step and workgroup (2 streams)\n")
+            f.write(txt + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--csv", default=None)
     ap.add_argument("--asm", default=None)
+    ap.add_argument("--int8", action="store_true", help="the int8 PARITY kernel of BASELINE config 4 (sample_kernel<2,32,true,false,true>) instead of the float one")
     a = ap.parse_args()
+    if a.int8:
+        return main_int8(a)
     path = a.asm
     if not path:
         path = os.path.join(tempfile.mkdtemp(prefix="lpcn_census_"), "k.s")
