@@ -262,9 +262,12 @@ typedef struct {
     int fail_code, fail_count;        /* sticky: first failed pass on this model (lpcnet_hip_model_status) */
 } registry_entry;
 #define COMB_MAX 256
-/* one waiting lpcnet_synthesize call */
+/* one waiting call of an entry point */
 typedef struct comb_req {
     LPCNetState *st; const float *feat; short *pcm; int N;
+    int kind, preload;                /* LPCN_GROUP_FRAME_SAMPLES / _TAIL / _FRAMES (lpcnet_engine.h) */
+    int want_products;                /* FRAME_SAMPLES: the frame products must come back (lpcnet_synthesize_impl; a combined pass always returns them) */
+    float *ga, *gb, *lpc;             /* the products: in (TAIL), out (FRAMES, FRAME_SAMPLES) */
     int done, rc;
     struct comb_req *next;
     char err[256];                    /* the leader's message for this caller (tl_err is thread-local) */
@@ -588,16 +591,6 @@ static int acquire_slot(registry_entry *r)
         pthread_mutex_unlock(&r->run_lock);
     }
 }
-/* The registry slot this state runs on, locked for one device round trip; NULL: *code, tl_err. */
-static registry_entry *acquire_entry(LPCNetState *st, int *code)
-{
-    registry_entry *r = pin_entry(st, code);                 /* (the pin keeps the slot from being evicted while we wait for it) */
-    if (!r) return NULL;
-    const int rc = acquire_slot(r);
-    unpin_entry(r);                                          /* (run_lock held: the slot is neither recycled nor evicted under it) */
-    if (rc) { *code = rc; return NULL; }
-    return r;
-}
 static void release_entry(registry_entry *r) { pthread_mutex_unlock(&r->run_lock); }
 
 /* upload the caller's POD state unless it is the copy the device already holds */
@@ -638,15 +631,20 @@ void lpcnet_reset_signal(LPCNetState *st)
     memset(st->s.gru_b, 0, sizeof(st->s.gru_b));
 }
 
-/* src/lpcnet.c:82-120: one step of the 100 Hz network; products go to the caller's arrays.  0 or a negative code (the
- * caller's state is untouched and nothing is written on failure). */
-static int frame_network_rc(LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features,
-                            registry_entry **rout)
+/* ---- combining dispatcher (round 4: lpcnet_synthesize; round 5: every entry point that touches the device) ---------------------------
+ * The reference is re-entrant per state: a server with one thread per stream scales over its cores.  Here every state of a model
+ * shares one device, so concurrent callers are COMBINED instead of serialised: a call queues itself on its model's slot; if no pass
+ * is being dispatched it becomes the leader, takes every queued call of its own shape -- same entry point, N and preload -- up to
+ * COMB_MAX, and runs them as ONE multi-stream pass (each caller's POD state up, kernels, states and results down, one
+ * synchronisation); calls that arrive meanwhile queue up and form the next pass, led by one of them -- group commit, no timer: a lone
+ * caller never waits for company, and under load a pass carries as many streams as arrived during the previous one.  Results are
+ * bit-identical to running the calls one by one (streams are independent).  The PLC-facing entry points (run_frame_network,
+ * lpcnet_synthesize_impl, lpcnet_synthesize_tail_impl: src/lpcnet_private.h:125-132, what a threaded PLC server calls through
+ * src/lpcnet_plc.c:216-239,378-421) go through the same queue as lpcnet_synthesize. */
+
+/* (run_lock held) the 100 Hz network for one state, serially; nothing is written unless it succeeded */
+static int frame_network_locked(registry_entry *r, LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features)
 {
-    int code = 0;
-    registry_entry *r = acquire_entry(st, &code);
-    *rout = r;
-    if (!r) return code;
     float lpc_new[LPCN_LPC_ORDER];      /* `lpc` may point into st->s, which the state download overwrites */
     float ga[LPCN_ROWS_A], gb[LPCN_ROWS_B];
     lpcn_stream_state snew;
@@ -654,19 +652,138 @@ static int frame_network_rc(LPCNetState *st, float *gru_a_condition, float *gru_
     r->cache_valid = 0;
     if (!rc) rc = lpcn_batch_dev_run_frames_host(r->dev, features, NB_FEATURES, ga, gb, lpc_new, 1);
     if (!rc) rc = pull_state(r, &snew);
-    if (rc) { r->cache_valid = 0; take_engine_err(); }
-    release_entry(r);
-    if (rc) return rc;
+    if (rc) { r->cache_valid = 0; return rc; }
     st->s = snew;
     memcpy(gru_a_condition, ga, sizeof(ga));
     memcpy(gru_b_condition, gb, sizeof(gb));
     memcpy(lpc, lpc_new, sizeof(lpc_new));
     return 0;
 }
+
+/* (run_lock held) N samples (any N: consecutive pieces of <= 160) from the products held in the state, serially */
+static int tail_locked(registry_entry *r, LPCNetState *st, short *output, int N, int preload)
+{
+    lpcn_stream_state snew;
+    int rc = push_state(r, &st->s);
+    r->cache_valid = 0;
+    short *tmp = (short *)malloc(sizeof(short) * (size_t)N);      /* (the caller's buffer is written only when every piece has succeeded) */
+    if (!tmp) { set_err("out of memory"); return LPCN_E_HIP; }
+    for (int done = 0; !rc && done < N; done += LPCN_FRAME_SIZE) {
+        const int n = N - done < LPCN_FRAME_SIZE ? N - done : LPCN_FRAME_SIZE;
+        const int pre = preload - done < 0 ? 0 : (preload - done > n ? n : preload - done);
+        short frame[LPCN_FRAME_SIZE] = {0};
+        memcpy(frame, output + done, sizeof(short) * (size_t)pre);
+        rc = lpcn_batch_dev_set_frame_len(r->dev, n);
+        if (!rc) rc = lpcn_batch_dev_run_tail_host(r->dev, st->gru_a_condition, st->gru_b_condition, st->s.lpc, frame, 1, pre);
+        /* live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243) */
+        if (!rc) memcpy(tmp + done, frame, sizeof(short) * (size_t)n);
+    }
+    if (!rc) rc = pull_state(r, &snew);
+    if (rc) { r->cache_valid = 0; free(tmp); return rc; }
+    st->s = snew;
+    memcpy(output, tmp, sizeof(short) * (size_t)N);
+    free(tmp);
+    return 0;
+}
+
+/* One device pass for `k` queued calls of one shape on one model (run_lock held by the caller through acquire_slot). */
+static int comb_run(registry_entry *r, comb_req **grp, int k)
+{
+    comb_req *q = grp[0];
+    if (k == 1) {                                            /* nobody to share with */
+        if (q->kind == LPCN_GROUP_FRAME_SAMPLES && q->preload == 0 && !q->want_products) {
+            /* lpcnet_synthesize alone: the single-stream fast path (state upload skipped when the device copy is current) */
+            const int fresh = !(r->cache_valid && memcmp(&r->cached, &q->st->s, sizeof(q->st->s)) == 0);
+            r->cache_valid = 0;
+            lpcn_stream_state snew;
+            int rc = lpcn_batch_dev_set_frame_len(r->dev, q->N);
+            if (!rc) rc = lpcn_batch_dev_run_single(r->dev, fresh ? &q->st->s : NULL, q->feat, q->pcm, &snew);
+            if (!rc) { q->st->s = snew; r->cached = snew; r->cache_valid = 1; }
+            return rc;
+        }
+        if (q->kind == LPCN_GROUP_FRAMES) return frame_network_locked(r, q->st, q->ga, q->gb, q->lpc, q->feat);
+        if (q->kind == LPCN_GROUP_TAIL) return tail_locked(r, q->st, q->pcm, q->N, q->preload);
+        /* lpcnet_synthesize_impl alone: the reference's two steps (src/lpcnet.c:273-277); atomic for the caller -- the state is put back
+         * if the second step fails */
+        const LPCNetState keep = *q->st;
+        int rc = frame_network_locked(r, q->st, q->ga, q->gb, q->lpc, q->feat);
+        if (!rc) rc = tail_locked(r, q->st, q->pcm, q->N, q->preload);
+        if (rc) *q->st = keep;
+        return rc;
+    }
+    if (!r->gdev) {
+        int rc = lpcn_batch_dev_create(&r->gdev, r->engine, COMB_MAX, 1);
+        if (rc) return rc;
+    }
+    const lpcn_stream_state *sin[COMB_MAX];
+    lpcn_stream_state *sout[COMB_MAX];
+    const float *ft[COMB_MAX];
+    short *pc[COMB_MAX];
+    float *ga[COMB_MAX], *gb[COMB_MAX], *lp[COMB_MAX];
+    for (int i = 0; i < k; i++) {
+        sin[i] = &grp[i]->st->s; sout[i] = &grp[i]->st->s; ft[i] = grp[i]->feat; pc[i] = grp[i]->pcm;
+        ga[i] = grp[i]->ga; gb[i] = grp[i]->gb; lp[i] = grp[i]->lpc;
+    }
+    r->cache_valid = 0;                                      /* (the one-stream batch's device copy is not what these states continue from) */
+    return lpcn_batch_dev_run_group(r->gdev, k, q->kind, q->N, q->preload, sin, ft, pc, sout, ga, gb, lp);      /* (writes only after the pass has succeeded) */
+}
+
+/* Queue one call on its model's slot and wait until a pass has served it (possibly leading that pass).  Returns 0 or a negative
+ * code (tl_err set; *rout = the slot, if one was resolved); nothing is written to the caller's memory on failure. */
+static int dispatch(comb_req *me, registry_entry **rout)
+{
+    /* the slot of this state's model, pinned while the call is queued (a pinned slot is neither evicted nor recycled) */
+    int code = 0;
+    registry_entry *r = pin_entry(me->st, &code);            /* (g_lock only: a pass in flight on this model must not keep other callers from queueing) */
+    *rout = r;
+    if (!r) return code;
+    pthread_mutex_lock(&r->q_lock);
+    if (r->q_tail) r->q_tail->next = me; else r->q_head = me;
+    r->q_tail = me;
+    while (!me->done) {
+        if (r->q_leader) { pthread_cond_wait(&r->q_cv, &r->q_lock); continue; }
+        /* lead one pass: my own call and everything queued with the same shape */
+        r->q_leader = 1;
+        comb_req *grp[COMB_MAX];
+        int k = 0;
+        grp[k++] = me;
+        comb_req **pp = &r->q_head, *last = NULL;
+        while (*pp) {
+            comb_req *q = *pp;
+            if (q == me || (q->kind == me->kind && q->N == me->N && q->preload == me->preload && q->N <= LPCN_FRAME_SIZE && k < COMB_MAX && q->st != me->st)) {
+                if (q != me) grp[k++] = q;
+                *pp = q->next;                               /* unlink */
+            } else { last = q; pp = &q->next; }
+        }
+        r->q_tail = last;
+        pthread_mutex_unlock(&r->q_lock);
+        int rc = acquire_slot(r);                            /* run_lock of THIS slot; re-creates the device side if it was released meanwhile */
+        if (!rc) {
+            rc = comb_run(r, grp, k);
+            if (rc) { r->cache_valid = 0; take_engine_err(); }
+            release_entry(r);
+        }
+        pthread_mutex_lock(&r->q_lock);
+        for (int i = 0; i < k; i++) {
+            grp[i]->rc = rc;
+            if (rc) snprintf(grp[i]->err, sizeof(grp[i]->err), "%.255s", tl_err);      /* (the message is thread-local: hand every caller its copy) */
+            grp[i]->done = 1;
+        }
+        r->q_leader = 0;
+        pthread_cond_broadcast(&r->q_cv);
+    }
+    pthread_mutex_unlock(&r->q_lock);
+    unpin_entry(r);
+    if (me->rc) snprintf(tl_err, sizeof(tl_err), "%s", me->err);
+    return me->rc;
+}
+
+/* src/lpcnet.c:82-120: one step of the 100 Hz network; products go to the caller's arrays (zeros on failure) */
 void run_frame_network(LPCNetState *st, float *gru_a_condition, float *gru_b_condition, float *lpc, const float *features)
 {
+    comb_req me = {st, features, NULL, LPCN_FRAME_SIZE, LPCN_GROUP_FRAMES, 0, 0, gru_a_condition, gru_b_condition, lpc, 0, 0, NULL, {0}};
     registry_entry *r = NULL;
-    const int rc = frame_network_rc(st, gru_a_condition, gru_b_condition, lpc, features, &r);
+    const int rc = dispatch(&me, &r);
     if (rc) {
         char why[sizeof(tl_err)];
         snprintf(why, sizeof(why), "%s", tl_err);
@@ -700,7 +817,7 @@ void run_frame_network_flush(LPCNetState *st)
 
 /* src/lpcnet.c:235-271: N samples from the products held in the state; the first `preload` samples of
  * `output` are imposed on the synthesis filter (teacher forcing) instead of being written.  Any N: the
- * sample loop does not care where a call ends, so N > 160 runs as consecutive pieces of <= 160 samples.
+ * sample loop does not care where a call ends, so N > 160 runs as consecutive pieces of <= 160 samples (never combined).
  * On failure the samples behind the imposed ones are zero-filled and the state is left as it was. */
 void lpcnet_synthesize_tail_impl(LPCNetState *st, short *output, int N, int preload)
 {
@@ -712,136 +829,47 @@ void lpcnet_synthesize_tail_impl(LPCNetState *st, short *output, int N, int prel
         entry_failed("lpcnet_synthesize_tail_impl", LPCN_E_ARG, NULL, why);
         return;
     }
-    int code = 0;
-    registry_entry *r = acquire_entry(st, &code);
-    int rc = r ? push_state(r, &st->s) : code;
-    lpcn_stream_state snew;
-    if (r) {
-        r->cache_valid = 0;
-        for (int done = 0; !rc && done < N; done += LPCN_FRAME_SIZE) {
-            const int n = N - done < LPCN_FRAME_SIZE ? N - done : LPCN_FRAME_SIZE;
-            const int pre = preload - done < 0 ? 0 : (preload - done > n ? n : preload - done);
-            short frame[LPCN_FRAME_SIZE] = {0};
-            memcpy(frame, output + done, sizeof(short) * (size_t)pre);
-            rc = lpcn_batch_dev_set_frame_len(r->dev, n);
-            if (!rc) rc = lpcn_batch_dev_run_tail_host(r->dev, st->gru_a_condition, st->gru_b_condition, st->s.lpc, frame, 1, pre);
-            /* live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243) */
-            if (!rc) memcpy(output + done, frame, sizeof(short) * (size_t)n);
-        }
-        if (!rc) rc = pull_state(r, &snew);
-        if (rc) { r->cache_valid = 0; take_engine_err(); }
-        release_entry(r);
-    }
+    comb_req me = {st, NULL, output, N, LPCN_GROUP_TAIL, preload, 0, st->gru_a_condition, st->gru_b_condition, st->s.lpc, 0, 0, NULL, {0}};
+    registry_entry *r = NULL;
+    const int rc = dispatch(&me, &r);
     if (rc) {
         char why[sizeof(tl_err)];
         snprintf(why, sizeof(why), "%s", tl_err);
         memset(output + preload, 0, sizeof(short) * (size_t)(N - preload));
         entry_failed("lpcnet_synthesize_tail_impl", rc, r, why);
-        return;
     }
-    st->s = snew;
 }
 
-/* src/lpcnet.c:273-277 */
+/* src/lpcnet.c:273-277: the frame network, then N samples; the frame products stay in the state for a later tail call */
 void lpcnet_synthesize_impl(LPCNetState *st, const float *features, short *output, int N, int preload)
 {
-    registry_entry *r = NULL;
-    const int rc = frame_network_rc(st, st->gru_a_condition, st->gru_b_condition, st->s.lpc, features, &r);
-    if (rc) {                                                /* no frame products: no samples either */
-        char why[sizeof(tl_err)];
-        snprintf(why, sizeof(why), "%s", tl_err);
-        if (N > 0 && preload >= 0 && preload <= N) memset(output + preload, 0, sizeof(short) * (size_t)(N - preload));
-        entry_failed("lpcnet_synthesize_impl", rc, r, why);
+    if (N > LPCN_FRAME_SIZE || N <= 0 || preload < 0 || preload > N) {      /* the reference's two steps, each with its own checks */
+        run_frame_network(st, st->gru_a_condition, st->gru_b_condition, st->s.lpc, features);
+        if (N > 0) lpcnet_synthesize_tail_impl(st, output, N, preload);
         return;
     }
-    lpcnet_synthesize_tail_impl(st, output, N, preload);
-}
-
-/* One device pass for `k` queued calls of one model (run_lock held by the caller through acquire_slot). */
-static int comb_run(registry_entry *r, comb_req **grp, int k)
-{
-    if (k == 1) {                                            /* nobody to share with: the single-stream fast path (state upload skipped when the device copy is current) */
-        comb_req *q = grp[0];
-        const int fresh = !(r->cache_valid && memcmp(&r->cached, &q->st->s, sizeof(q->st->s)) == 0);
-        r->cache_valid = 0;
-        lpcn_stream_state snew;
-        int rc = lpcn_batch_dev_set_frame_len(r->dev, q->N);
-        if (!rc) rc = lpcn_batch_dev_run_single(r->dev, fresh ? &q->st->s : NULL, q->feat, q->pcm, &snew);
-        if (!rc) { q->st->s = snew; r->cached = snew; r->cache_valid = 1; }
-        return rc;
+    comb_req me = {st, features, output, N, LPCN_GROUP_FRAME_SAMPLES, preload, 1, st->gru_a_condition, st->gru_b_condition, st->s.lpc, 0, 0, NULL, {0}};
+    registry_entry *r = NULL;
+    const int rc = dispatch(&me, &r);
+    if (rc) {
+        char why[sizeof(tl_err)];
+        snprintf(why, sizeof(why), "%s", tl_err);
+        memset(output + preload, 0, sizeof(short) * (size_t)(N - preload));
+        entry_failed("lpcnet_synthesize_impl", rc, r, why);
     }
-    if (!r->gdev) {
-        int rc = lpcn_batch_dev_create(&r->gdev, r->engine, COMB_MAX, 1);
-        if (rc) return rc;
-    }
-    const lpcn_stream_state *sin[COMB_MAX];
-    lpcn_stream_state *sout[COMB_MAX];
-    const float *ft[COMB_MAX];
-    short *pc[COMB_MAX];
-    for (int i = 0; i < k; i++) { sin[i] = &grp[i]->st->s; sout[i] = &grp[i]->st->s; ft[i] = grp[i]->feat; pc[i] = grp[i]->pcm; }
-    r->cache_valid = 0;                                      /* (the one-stream batch's device copy is not what these states continue from) */
-    return lpcn_batch_dev_run_group(r->gdev, k, grp[0]->N, sin, ft, pc, sout);      /* (writes states and PCM only after the pass has succeeded) */
 }
 
 /* src/lpcnet.c:279-281.  N <= 160 (every caller in the reference): one fused device pass -- frame kernels and sample
  * kernel back to back, one synchronisation; bit-identical to lpcnet_synthesize_impl(..., 0) (tests/test_gpu_parity.py).
  * N > 160: the reference runs the frame network once and then N samples; so does the two-step form.
- *
- * Combining dispatcher (round 4).  The reference is re-entrant per state: a server with one thread per stream scales over
- * its cores.  Here every state of a model shares one device, so concurrent callers are COMBINED instead of serialised: a
- * call queues itself on its model's slot; if no pass is being dispatched it becomes the leader, takes every queued call
- * with its own N (up to COMB_MAX), and runs them as ONE multi-stream pass (each caller's POD state up, frame + sample
- * kernels, states and PCM down); calls that arrive meanwhile queue up and form the next pass, led by one of them -- group
- * commit, no timer: a lone caller never waits for company, and under load a pass carries as many streams as arrived during
- * the previous one.  Results are bit-identical to running the calls one by one (streams are independent).
+ * One difference a caller of the INTERNAL entry points could observe: a lone lpcnet_synthesize call does not refresh the frame
+ * products kept in the state (gru_a_condition / gru_b_condition: 4.8 KB more to download per frame on the single-stream fast path);
+ * a lpcnet_synthesize_tail_impl that continues a frame must follow lpcnet_synthesize_impl, as it does in src/lpcnet_plc.c.
  * Returns 0 or a negative code (tl_err set; *rout = the slot, if one was resolved); nothing is written on failure. */
 static int synthesize_rc(LPCNetState *st, const float *features, short *output, int N, registry_entry **rout)
 {
-    /* the slot of this state's model, pinned while the call is queued (a pinned slot is neither evicted nor recycled) */
-    int code = 0;
-    registry_entry *r = pin_entry(st, &code);                /* (g_lock only: a pass in flight on this model must not keep other callers from queueing) */
-    *rout = r;
-    if (!r) return code;
-    comb_req me = {st, features, output, N, 0, 0, NULL, {0}};
-    pthread_mutex_lock(&r->q_lock);
-    if (r->q_tail) r->q_tail->next = &me; else r->q_head = &me;
-    r->q_tail = &me;
-    while (!me.done) {
-        if (r->q_leader) { pthread_cond_wait(&r->q_cv, &r->q_lock); continue; }
-        /* lead one pass: my own call and everything queued with the same N */
-        r->q_leader = 1;
-        comb_req *grp[COMB_MAX];
-        int k = 0;
-        grp[k++] = &me;
-        comb_req **pp = &r->q_head, *last = NULL;
-        while (*pp) {
-            comb_req *q = *pp;
-            if (q == &me || (q->N == N && k < COMB_MAX && q->st != st)) {
-                if (q != &me) grp[k++] = q;
-                *pp = q->next;                               /* unlink */
-            } else { last = q; pp = &q->next; }
-        }
-        r->q_tail = last;
-        pthread_mutex_unlock(&r->q_lock);
-        int rc = acquire_slot(r);                            /* run_lock of THIS slot; re-creates the device side if it was released meanwhile */
-        if (!rc) {
-            rc = comb_run(r, grp, k);
-            if (rc) { r->cache_valid = 0; take_engine_err(); }
-            release_entry(r);
-        }
-        pthread_mutex_lock(&r->q_lock);
-        for (int i = 0; i < k; i++) {
-            grp[i]->rc = rc;
-            if (rc) snprintf(grp[i]->err, sizeof(grp[i]->err), "%.255s", tl_err);      /* (the message is thread-local: hand every caller its copy) */
-            grp[i]->done = 1;
-        }
-        r->q_leader = 0;
-        pthread_cond_broadcast(&r->q_cv);
-    }
-    pthread_mutex_unlock(&r->q_lock);
-    unpin_entry(r);
-    if (me.rc) snprintf(tl_err, sizeof(tl_err), "%s", me.err);
-    return me.rc;
+    comb_req me = {st, features, output, N, LPCN_GROUP_FRAME_SAMPLES, 0, 0, st->gru_a_condition, st->gru_b_condition, st->s.lpc, 0, 0, NULL, {0}};
+    return dispatch(&me, rout);
 }
 
 void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)

@@ -720,43 +720,81 @@ extern "C" int lpcn_batch_dev_run_single(lpcn_batch_dev *b, const lpcn_stream_st
     return 0;
 }
 
-// Combined pass of the legacy per-frame API (api.c: lpcnet_synthesize callers of one model that arrive while a pass is in
-// flight are served together): k <= capacity independent streams, each with its caller's POD state, one frame of features
-// and frame_len samples -- states up, frame kernels + sample kernel, states and PCM down, ONE synchronisation.  The batch
-// was created with the capacity as its stream count; a pass uses its first k slots.
-extern "C" int lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int frame_len, const lpcn_stream_state *const *st_in, const float *const *feat,
-                                        short *const *pcm, lpcn_stream_state *const *st_out)
+// Combined pass of the legacy per-frame API (api.c: callers of one model that arrive while a pass is in flight are served together):
+// k <= capacity independent streams, each with its caller's POD state -- states up, kernels, states and results down, ONE
+// synchronisation.  The batch was created with the capacity as its stream count; a pass uses its first k slots.  `kind`:
+//   LPCN_GROUP_FRAME_SAMPLES  frame network on feat[i] + frame_len samples (lpcnet_synthesize / lpcnet_synthesize_impl, src/lpcnet.c:273-281);
+//                             the first `preload` samples of pcm[i] are imposed (teacher forcing); the frame products come back in
+//                             ga[i] / gb[i] (the reference keeps them in the state for a later tail call; lpc is part of the state record)
+//   LPCN_GROUP_TAIL           frame_len samples from the caller's products ga[i] / gb[i] / lpc[i] (lpcnet_synthesize_tail_impl, :235-271)
+//   LPCN_GROUP_FRAMES         frame network only; products returned in ga[i] / gb[i] / lpc[i] (run_frame_network, :82-120)
+// Nothing is written to the callers' memory unless the whole pass succeeded.
+extern "C" int lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int kind, int frame_len, int preload, const lpcn_stream_state *const *st_in,
+                                        const float *const *feat, short *const *pcm, lpcn_stream_state *const *st_out,
+                                        float *const *ga, float *const *gb, float *const *lpc)
 {
-    if (k < 1 || frame_len < 1 || frame_len > LPCN_FRAME_SIZE) { snprintf(g_err, sizeof(g_err), "bad group arguments"); return LPCN_E_ARG; }
+    const bool samples = kind != LPCN_GROUP_FRAMES, frames = kind != LPCN_GROUP_TAIL;
+    if (k < 1 || kind < 0 || kind > 2 || (samples && (frame_len < 1 || frame_len > LPCN_FRAME_SIZE || preload < 0 || preload > frame_len))) {
+        snprintf(g_err, sizeof(g_err), "bad group arguments"); return LPCN_E_ARG;
+    }
     DeviceGuard guard(b->e->device);
     const int cap = b->n;
     if (k > cap) { snprintf(g_err, sizeof(g_err), "group of %d exceeds the batch's %d streams", k, cap); return LPCN_E_ARG; }
     int rc = ensure_staging(b, (size_t)cap * LPCN_NB_FEAT, (size_t)cap * LPCN_FRAME_SIZE);
     if (rc) return rc;
+    // pinned staging: states | features | pcm | cond_a | cond_b | lpc, each for `cap` streams
     const size_t sz_st = sizeof(lpcn_stream_state), off_feat = sz_st * cap, off_pcm = off_feat + sizeof(float) * LPCN_NB_FEAT * cap;
-    if (!b->h_pin) HIP_TRY(hipHostMalloc(&b->h_pin, off_pcm + sizeof(short) * LPCN_FRAME_SIZE * cap, hipHostMallocDefault));
+    const size_t off_ga = off_pcm + sizeof(short) * LPCN_FRAME_SIZE * cap, off_gb = off_ga + sizeof(float) * LPCN_ROWS_A * cap;
+    const size_t off_lpc = off_gb + sizeof(float) * LPCN_ROWS_B * cap, pin_bytes = off_lpc + sizeof(float) * LPCN_LPC_ORDER * cap;
+    if (!b->h_pin) HIP_TRY(hipHostMalloc(&b->h_pin, pin_bytes, hipHostMallocDefault));
     hipStream_t st = b->e->stream;
     if ((rc = order_begin(b, st))) return rc;
     unsigned char *pin = (unsigned char *)b->h_pin;
     for (int i = 0; i < k; ++i) {
         memcpy(pin + sz_st * i, st_in[i], sz_st);
-        memcpy(pin + off_feat + sizeof(float) * LPCN_NB_FEAT * i, feat[i], sizeof(float) * LPCN_NB_FEAT);
+        if (frames) memcpy(pin + off_feat + sizeof(float) * LPCN_NB_FEAT * i, feat[i], sizeof(float) * LPCN_NB_FEAT);
+        if (samples && preload > 0) memcpy(pin + off_pcm + sizeof(short) * LPCN_FRAME_SIZE * i, pcm[i], sizeof(short) * (size_t)preload);
+        if (kind == LPCN_GROUP_TAIL) {
+            memcpy(pin + off_ga + sizeof(float) * LPCN_ROWS_A * i, ga[i], sizeof(float) * LPCN_ROWS_A);
+            memcpy(pin + off_gb + sizeof(float) * LPCN_ROWS_B * i, gb[i], sizeof(float) * LPCN_ROWS_B);
+            memcpy(pin + off_lpc + sizeof(float) * LPCN_LPC_ORDER * i, lpc[i], sizeof(float) * LPCN_LPC_ORDER);
+        }
     }
     HIP_TRY(hipMemcpyAsync(b->d_state, pin, sz_st * k, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b->d_feat, pin + off_feat, sizeof(float) * LPCN_NB_FEAT * k, hipMemcpyHostToDevice, st));
+    if (frames) HIP_TRY(hipMemcpyAsync(b->d_feat, pin + off_feat, sizeof(float) * LPCN_NB_FEAT * k, hipMemcpyHostToDevice, st));
+    if (samples && preload > 0) HIP_TRY(hipMemcpyAsync(b->d_pcm, pin + off_pcm, sizeof(short) * LPCN_FRAME_SIZE * k, hipMemcpyHostToDevice, st));
+    if (kind == LPCN_GROUP_TAIL) {     // (one frame per stream: the chunk buffers are dense [stream][...])
+        HIP_TRY(hipMemcpyAsync(b->d_cond_a, pin + off_ga, sizeof(float) * LPCN_ROWS_A * k, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_cond_b, pin + off_gb, sizeof(float) * LPCN_ROWS_B * k, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_lpc, pin + off_lpc, sizeof(float) * LPCN_LPC_ORDER * k, hipMemcpyHostToDevice, st));
+    }
     const int keepS = b->S, keep_len = b->frame_len;
     const bool keepP = b->pack2, keepA = b->S_auto, keepT = b->tuned;
-    b->n = k; b->frame_len = frame_len; b->S = auto_streams_per_wg(b->e, k); b->pack2 = use_pack2(b->e, k, b->S); b->S_auto = false; b->tuned = true;
-    rc = run_impl(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, 0, st, false);      // (S comes from the table for the group's size)
+    b->n = k; b->frame_len = samples ? frame_len : keep_len; b->S = auto_streams_per_wg(b->e, k); b->pack2 = use_pack2(b->e, k, b->S); b->S_auto = false; b->tuned = true;
+    if (!b->keep_ok.empty()) b->keep_ok.assign(b->keep_ok.size(), 0);
+    if (kind == LPCN_GROUP_FRAME_SAMPLES) rc = run_impl(b, b->d_feat, LPCN_NB_FEAT, b->d_pcm, 1, preload, st, false);      // (S comes from the table for the group's size)
+    else if (kind == LPCN_GROUP_TAIL) rc = launch_sample(b, st, b->d_pcm, (size_t)LPCN_FRAME_SIZE, 1, preload, false);
+    else rc = launch_frames(b, st, b->d_feat, LPCN_NB_FEAT, (size_t)LPCN_NB_FEAT, 1);
     b->n = cap; b->frame_len = keep_len; b->S = keepS; b->pack2 = keepP; b->S_auto = keepA; b->tuned = keepT;
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pin, b->d_state, sz_st * k, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(pin + off_pcm, b->d_pcm, sizeof(short) * LPCN_FRAME_SIZE * k, hipMemcpyDeviceToHost, st));
+    if (samples) HIP_TRY(hipMemcpyAsync(pin + off_pcm, b->d_pcm, sizeof(short) * LPCN_FRAME_SIZE * k, hipMemcpyDeviceToHost, st));
+    if (frames) {
+        HIP_TRY(hipMemcpyAsync(pin + off_ga, b->d_cond_a, sizeof(float) * LPCN_ROWS_A * k, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(pin + off_gb, b->d_cond_b, sizeof(float) * LPCN_ROWS_B * k, hipMemcpyDeviceToHost, st));
+        if (kind == LPCN_GROUP_FRAMES) HIP_TRY(hipMemcpyAsync(pin + off_lpc, b->d_lpc, sizeof(float) * LPCN_LPC_ORDER * k, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     b->pending = false;
     for (int i = 0; i < k; ++i) {
         memcpy(st_out[i], pin + sz_st * i, sz_st);
-        memcpy(pcm[i], pin + off_pcm + sizeof(short) * LPCN_FRAME_SIZE * i, sizeof(short) * (size_t)frame_len);
+        // live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243)
+        if (samples) memcpy(pcm[i], pin + off_pcm + sizeof(short) * LPCN_FRAME_SIZE * i, sizeof(short) * (size_t)frame_len);
+        if (frames) {
+            memcpy(ga[i], pin + off_ga + sizeof(float) * LPCN_ROWS_A * i, sizeof(float) * LPCN_ROWS_A);
+            memcpy(gb[i], pin + off_gb + sizeof(float) * LPCN_ROWS_B * i, sizeof(float) * LPCN_ROWS_B);
+            if (kind == LPCN_GROUP_FRAMES) memcpy(lpc[i], pin + off_lpc + sizeof(float) * LPCN_LPC_ORDER * i, sizeof(float) * LPCN_LPC_ORDER);
+        }
     }
     return 0;
 }

@@ -128,8 +128,14 @@ int  lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n_streams, 
 void lpcn_batch_dev_destroy(lpcn_batch_dev *b);
 int  lpcn_batch_dev_reset(lpcn_batch_dev *b, int first, int count);           /* lpcnet_reset   */
 int  lpcn_batch_dev_get_state(lpcn_batch_dev *b, int stream, lpcn_stream_state *host);
-int  lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int frame_len, const lpcn_stream_state *const *st_in, const float *const *feat,
-                              short *const *pcm, lpcn_stream_state *const *st_out);      /* k independent streams, one frame each, one synchronisation */
+/* k independent streams with their callers' POD states in ONE pass and one synchronisation (engine.hip): frame network + samples,
+ * samples from the callers' frame products, or the frame network alone */
+#define LPCN_GROUP_FRAME_SAMPLES 0
+#define LPCN_GROUP_TAIL          1
+#define LPCN_GROUP_FRAMES        2
+int  lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int kind, int frame_len, int preload, const lpcn_stream_state *const *st_in,
+                              const float *const *feat, short *const *pcm, lpcn_stream_state *const *st_out,
+                              float *const *ga, float *const *gb, float *const *lpc);
 int  lpcn_batch_dev_tune(lpcn_batch_dev *b);              /* measure the streams per workgroup now, on the engine's own stream */
 int  lpcn_batch_dev_set_state(lpcn_batch_dev *b, int stream, const lpcn_stream_state *host);
 int  lpcn_batch_dev_streams_per_wg(const lpcn_batch_dev *b);

@@ -127,6 +127,9 @@ template <typename T> __device__ __forceinline__ LPCN_GLOBAL T *as_global_rw(T *
 #define LPCN_REMAT_V(x) asm volatile("" : "+v"(x))
 #define LPCN_REMAT_S(x) asm volatile("" : "+s"(x))
 
+#ifndef LPCN_ROW_LDS
+#define LPCN_ROW_LDS 0          // 1: the lane's row numbers live in LDS instead of three VGPRs (measured in round 4: 122.7 vs 124.8 M -- slower; the table then costs 6 KB)
+#endif
 // ---- LDS carve-up (bytes), all offsets multiples of 16 ---------------------------------------
 #ifndef LPCN_PROD_BLOCKS
 #define LPCN_PROD_BLOCKS 48
@@ -160,7 +163,7 @@ template <int S> struct Lds {
     static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
     static constexpr int rowtab = boff + 1216;                      // [3][512] i32: the rows a lane owns (-1: none) -- an LDS read where a VGPR would be spilled to scratch
-    static constexpr int bw     = rowtab + 3 * LPCN_WG_THREADS * 4; // [nb_b padded][8][4] f32
+    static constexpr int bw     = rowtab + (LPCN_ROW_LDS ? 3 * LPCN_WG_THREADS * 4 : 0); // [nb_b padded][8][4] f32   (round 5: the row table is only carved out when it is used -- it was 6 KB of dead LDS in every variant)
     static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 28 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
     // single-stream PARITY float: idle waves hand GRU-B's chain wave the PRODUCTS of the last PROD_BLOCKS blocks through LDS
     // ([block][48 rows] float4, 768 B per block) -- the chain then costs one read + four adds per block instead of two reads, two
@@ -373,12 +376,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // ------------------------------------------------------------------ resident weights ----
     WT w[NW];
     uint32_t offp[(NW + 1) / 2];
-#ifndef LPCN_ROW_LDS
-#define LPCN_ROW_LDS 0          // the lane's row numbers live in LDS (the PARITY float kernels spilled them to scratch and re-read them at every slot boundary)
-#endif
     int row_reg[3];
-    const int *const sm_row = (const int *)(smem + L::rowtab) + tid0;
 #if LPCN_ROW_LDS
+    const int *const sm_row = (const int *)(smem + L::rowtab) + tid0;
 #define LPCN_ROW(k) (sm_row[(k) * LPCN_WG_THREADS])
 #else
 #define LPCN_ROW(k) (row_reg[k])
@@ -411,7 +411,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         }
         const auto *ar = as_global(Ap->a_row);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { row_reg[k] = ar[(wave * 3 + k) * 64 + lane]; ((int *)(smem + L::rowtab))[k * LPCN_WG_THREADS + tid0] = row_reg[k]; }
+        for (int k = 0; k < 3; ++k) {
+            row_reg[k] = ar[(wave * 3 + k) * 64 + lane];
+#if LPCN_ROW_LDS
+            ((int *)(smem + L::rowtab))[k * LPCN_WG_THREADS + tid0] = row_reg[k];
+#endif
+        }
     }
     int b1 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 1]);
     int b2 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 2]);

@@ -176,3 +176,83 @@ def test_unmodified_reference_plc_runs_on_the_engine_bit_exact(options, hip_lib)
     assert np.abs(concealed.astype(np.int32)).max() > 50      # the concealment really synthesised something
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, (int(bad[0]) // 160, int(bad[0]) % 160, int(bad.size))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern,min_speedup", [("burst", 6.0), ("staggered", 2.0)])
+def test_threaded_plc_server_combines_the_plc_facing_entry_points(pattern, min_speedup, hip_lib):
+    """a packet-loss-concealment server with one thread per stream.  32 threads each run the reference's UNMODIFIED
+    src/lpcnet_plc.c on the engine through their own loss pattern; the entry points it calls -- run_frame_network (through the deferred
+    queue), lpcnet_synthesize_impl, lpcnet_synthesize_tail_impl (src/lpcnet_private.h:125-132, src/lpcnet_plc.c:216-239,378-421) -- are
+    combined into multi-stream passes like lpcnet_synthesize.  Every thread must return, sample for sample, what the reference's own
+    generic-C build returns for its signal and losses.  Calls combine when they have the same shape (entry point, N, preload) at the
+    same time: `burst` = the same frames are lost on every stream (a network outage), where the threads fall into step and the 32
+    together are served at many times one thread's rate; `staggered` = every stream has its own loss times, where only the calls
+    that happen to coincide share a pass."""
+    import ctypes as C
+    import sys
+    import threading
+    import time
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "liblpcnet_ref_gf.so")
+    plc_path = os.path.join(ROOT, "oracle", "_ref", "liblpcnet_plc_hip.so")
+    if not (os.path.exists(ref_path) and os.path.exists(plc_path)):
+        pytest.skip("oracle/_ref/liblpcnet_plc_hip.so / liblpcnet_ref_gf.so not built (needs the reference tree)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import plc_synth
+    from lpcnet_amd import api
+    blob = synth.blob_bytes(plc_synth.make_model_with_plc())
+    NT, T = 32, 36
+    feats = np.stack([synth.make_features(4300 + i, T + 4) for i in range(NT)])
+    b = api.LPCNetBatch(NT, blob)
+    signals = b.synthesize(feats)[:, 4 * 160:]
+    b.close()
+    if pattern == "burst":
+        lost = [[t % 9 in (6, 7) or t in (20, 21, 22) for t in range(T)] for i in range(NT)]
+    else:
+        lost = [[(t + 2 * i) % 9 in (6, 7) or (t in (20, 21, 22) and i % 3 == 0) for t in range(T)] for i in range(NT)]
+
+    def bind(path):
+        lib = C.CDLL(path)
+        lib.lpcnet_plc_create.restype = C.c_void_p
+        lib.lpcnet_plc_create.argtypes = [C.c_int]
+        lib.lpcnet_plc_load_model.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.lpcnet_plc_update.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lpcnet_plc_conceal.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lpcnet_plc_destroy.argtypes = [C.c_void_p]
+        return lib
+
+    buf = C.create_string_buffer(blob, len(blob))             # must outlive the states (the reference keeps pointers into it)
+
+    def run_one(lib, i, out):
+        st = lib.lpcnet_plc_create(0)
+        assert lib.lpcnet_plc_load_model(st, buf, len(blob)) == 0
+        for t in range(T):
+            frame = np.ascontiguousarray(signals[i, t * 160:(t + 1) * 160]).copy()
+            (lib.lpcnet_plc_conceal if lost[i][t] else lib.lpcnet_plc_update)(st, frame.ctypes.data)
+            out[t * 160:(t + 1) * 160] = frame
+        lib.lpcnet_plc_destroy(st)
+
+    ref, eng = bind(ref_path), bind(plc_path)
+    want = np.zeros((NT, T * 160), np.int16)
+    for i in range(NT):
+        run_one(ref, i, want[i])
+    api.clear_error()
+    warm = np.zeros(T * 160, np.int16)
+    run_one(eng, 0, warm)                                     # model upload, kernel load
+    assert np.array_equal(warm, want[0])
+    t0 = time.perf_counter()
+    alone = np.zeros(T * 160, np.int16)
+    run_one(eng, 1, alone)
+    t_one = time.perf_counter() - t0
+    got = np.zeros((NT, T * 160), np.int16)
+    ths = [threading.Thread(target=run_one, args=(eng, i, got[i])) for i in range(NT)]
+    t0 = time.perf_counter()
+    for th in ths: th.start()
+    for th in ths: th.join()
+    t_all = time.perf_counter() - t0
+    bad = [i for i in range(NT) if not np.array_equal(got[i], want[i])]
+    assert not bad, bad
+    assert np.array_equal(alone, want[1])
+    speedup = NT * t_one / t_all
+    print(f"threaded PLC ({pattern}): one stream {t_one * 1e3:.0f} ms, {NT} threads {t_all * 1e3:.0f} ms -> {speedup:.1f} x one thread's rate")
+    assert speedup >= min_speedup, (t_one, t_all)
