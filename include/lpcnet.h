@@ -105,6 +105,10 @@ LPCNET_EXPORT void lpcnet_hip_clear_error(void);
  * cleared (clear != 0 resets it).  A server thread that shares a model with others learns here that some caller's pass
  * failed -- under the combining dispatcher one failed pass fails every call it carried. */
 LPCNET_EXPORT int lpcnet_hip_model_status(const LPCNetState *st, int clear);
+/* Combining dispatcher of the per-state entry points (lpcnet_synthesize, lpcnet_synthesize_impl / _tail_impl, run_frame_network):
+ * out3 = {calls served, device passes that served them, calls in the largest pass} since the process started or the last reset.
+ * calls / passes > 1 means concurrent callers of one model were served together. */
+LPCNET_EXPORT int lpcnet_hip_dispatch_stats(unsigned long long *out3, int reset);
 /* "src=<hash> dev=<hash>": sha1 prefixes of the sources this library was built from (all of lpcnet_amd/csrc + include, and
  * the device sources alone); bench.py echoes them so that a measurement can be tied to the tree it claims */
 LPCNET_EXPORT const char *lpcnet_hip_build_info(void);

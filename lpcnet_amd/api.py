@@ -120,6 +120,7 @@ def load_library():
     L.lpcnet_hip_clear_error.restype = None
     L.lpcnet_hip_model_status.argtypes = [vp, C.c_int]
     L.lpcnet_hip_build_info.restype = C.c_char_p
+    L.lpcnet_hip_dispatch_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     _lib = L
     return L
 
@@ -148,6 +149,13 @@ def build_info() -> dict:
     """{'src': hash of every source the library was built from, 'dev': hash of the device sources alone}"""
     txt = load_library().lpcnet_hip_build_info().decode()
     return dict(kv.split("=", 1) for kv in txt.split())
+
+
+def dispatch_stats(reset=False):
+    """(calls served, device passes, calls in the largest pass) of the combining dispatcher behind the per-state entry points"""
+    out = (C.c_ulonglong * 3)()
+    load_library().lpcnet_hip_dispatch_stats(out, 1 if reset else 0)
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def quant_sweep():

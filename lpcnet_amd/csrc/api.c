@@ -728,6 +728,23 @@ static int comb_run(registry_entry *r, comb_req **grp, int k)
     return lpcn_batch_dev_run_group(r->gdev, k, q->kind, q->N, q->preload, sin, ft, pc, sout, ga, gb, lp);      /* (writes only after the pass has succeeded) */
 }
 
+/* dispatcher statistics (process-wide, relaxed atomics): calls served, device passes that served them, the largest pass */
+static unsigned long long g_disp_calls, g_disp_passes, g_disp_max;
+int lpcnet_hip_dispatch_stats(unsigned long long *out3, int reset)
+{
+    if (out3) {
+        out3[0] = __atomic_load_n(&g_disp_calls, __ATOMIC_RELAXED);
+        out3[1] = __atomic_load_n(&g_disp_passes, __ATOMIC_RELAXED);
+        out3[2] = __atomic_load_n(&g_disp_max, __ATOMIC_RELAXED);
+    }
+    if (reset) {
+        __atomic_store_n(&g_disp_calls, 0ull, __ATOMIC_RELAXED);
+        __atomic_store_n(&g_disp_passes, 0ull, __ATOMIC_RELAXED);
+        __atomic_store_n(&g_disp_max, 0ull, __ATOMIC_RELAXED);
+    }
+    return 0;
+}
+
 /* Queue one call on its model's slot and wait until a pass has served it (possibly leading that pass).  Returns 0 or a negative
  * code (tl_err set; *rout = the slot, if one was resolved); nothing is written to the caller's memory on failure. */
 static int dispatch(comb_req *me, registry_entry **rout)
@@ -757,6 +774,12 @@ static int dispatch(comb_req *me, registry_entry **rout)
         }
         r->q_tail = last;
         pthread_mutex_unlock(&r->q_lock);
+        __atomic_fetch_add(&g_disp_calls, (unsigned long long)k, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_disp_passes, 1ull, __ATOMIC_RELAXED);
+        {
+            unsigned long long mx = __atomic_load_n(&g_disp_max, __ATOMIC_RELAXED);
+            while ((unsigned long long)k > mx && !__atomic_compare_exchange_n(&g_disp_max, &mx, (unsigned long long)k, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+        }
         int rc = acquire_slot(r);                            /* run_lock of THIS slot; re-creates the device side if it was released meanwhile */
         if (!rc) {
             rc = comb_run(r, grp, k);

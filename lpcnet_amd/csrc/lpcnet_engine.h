@@ -41,7 +41,26 @@ extern "C" {
 #define LPCN_MAX_SLOTS  3
 #define LPCN_EARLY_MAX  24     /* most items of a candidate slot that waves 4..7 may compute one sample ahead (float blobs) */
 #define LPCN_DEAL_EH_F32 24    /* float blobs: head length of the early candidate items (round 4, matrix-pipe items: 20 / 22 / 24 -> 121.3 / 123.5 / 123.9 M samples/s) */
-#define LPCN_DEAL_HW_I8 3      /* int8 blobs: first wave that may carry a candidate head (model_pack.c; 4 / 3 / 2 -> 153.4 / 156.2 / 154.1 M samples/s) */
+#define LPCN_DEAL_HW_I8 3      /* int8 blobs: first wave that may carry a candidate head (model_pack.c; 4 / 3 / 2 -> 153.4 / 156.2 / 154.1 M samples/s; round 5: superseded by the mask below) */
+/* int8 blobs, PARITY, <= 2 streams per workgroup (two workgroups per CU -- the operating point of a full GPU): GRU-B's chain waves are
+ * LPCN_I8_GBWA (stream 0) and LPCN_I8_GBWB (stream 1), NOT waves 0 and 1.  Waves w and w + 4 share a SIMD and wave 0 also leads the
+ * streams (tree walk, LPC, mu-law: ~380 VALU instructions per sample that no other wave has); with GRU-B (~410 per stream) on waves
+ * 0 / 1 as well, the SIMD of waves 0 / 4 issues 1.9 k VALU instructions per step against 1.2 k on the SIMDs of waves 2 / 6 and 3 / 7
+ * (tools/valu_census.py --int8), and two co-resident workgroups are bound by the busiest SIMD (tools/ubench/hwid.hip: the second
+ * workgroup's wave w lands one SIMD further than the first one's).  Every other wave is idle in GRU-B's phase and carries a
+ * candidate head (LPCN_DEAL_HMASK_I8: bit w = wave w may), LPCN_DEAL_EH_I8 items long.  Measured (1024 streams, bit-exact):
+ * waves 0,1 / 2,3 / 1,3 / 1,2 -> 157.6 / 163.3 / 160.7 / 160.1 M samples/s; head 10 / 14 / 16 / 18 / 20 / 22 / 24 items with 2,3 ->
+ * 157.3 / 163.3 / 166.1 / 167.9 / 164.6 / 169.0 / 168.3 M (gpurun_out of round 5, two runs each within 0.2 M). */
+#ifndef LPCN_I8_GBWA
+#define LPCN_I8_GBWA 2
+#define LPCN_I8_GBWB 3
+#endif
+#ifndef LPCN_DEAL_HMASK_I8
+#define LPCN_DEAL_HMASK_I8 (0xFFu & ~((1u << LPCN_I8_GBWA) | (1u << LPCN_I8_GBWB)))
+#endif
+#ifndef LPCN_DEAL_EH_I8
+#define LPCN_DEAL_EH_I8 22
+#endif
 #define LPCN_DEAL_EH_FAST_I8 0 /* head length of the FAST arithmetic's own image of int8 blobs (model_pack.c: lpcn_model_pack_fast) */
 
 typedef struct lpcn_model_host {

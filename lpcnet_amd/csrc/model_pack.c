@@ -95,13 +95,14 @@ typedef struct { int items[LPCN_WAVES], nsl[LPCN_WAVES], nzr[LPCN_WAVES], cand[L
 typedef struct {
     int eh;                     /* head length of the early candidate items */
     int hw;                     /* first wave that may carry a candidate head (float: 4 = the waves that never run GRU-B; int8: see pack_gru_a) */
+    unsigned hmask;             /* bit w: wave w may carry a candidate head (default: the waves >= hw) */
     int tg, t0a, t0b, ci, cu;   /* deal_wave_cost */
     int tl;                     /* wave 0 leads the streams: its own part of GRU-A starts this much later */
 } deal_params;
 
 static int deal_head(const deal_params *dp, int w, int cand)
 {
-    if (w < dp->hw || cand <= 0) return 0;
+    if (!((dp->hmask >> w) & 1u) || cand <= 0) return 0;
     const int eh = dp->eh < LPCN_EARLY_MAX ? dp->eh : LPCN_EARLY_MAX;
     return cand < eh ? cand : eh;
 }
@@ -117,7 +118,7 @@ static long deal_wave_cost(const deal_params *dp, const deal_state *d, int w)
     const long after_gather = dp->tg + (w == 0 ? dp->tl : 0) + (long)dp->cu * d->zr_items[w];
     long t;
     if (tail >= 10) {
-        t = (w < dp->hw ? dp->t0a : dp->t0b) + (w == 0 ? dp->tl : 0) + (long)dp->ci * (tail + d->zr_items[w]);
+        t = (!((dp->hmask >> w) & 1u) ? dp->t0a : dp->t0b) + (w == 0 ? dp->tl : 0) + (long)dp->ci * (tail + d->zr_items[w]);
         if (t < after_gather) t = after_gather;
     } else {
         t = after_gather + (long)dp->cu * tail;
@@ -211,15 +212,21 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
     const int deal2 = !m->is_int8 || !(old_i8 && old_i8[0] == '1');      /* split candidate chains (see deal_wave_cost) */
     {
         const char *eh = getenv("LPCN_DEAL_EH");          /* tools: head length of the early candidate items (float default 20: 18 / 20 / 22 / 24 -> 104.4 / 105.0 / 104.1 / 103.3 M samples/s) */
-        dp->eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? 14 : LPCN_DEAL_EH_F32);     /* int8: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s (two workgroups of two streams per CU) */
-        {   /* int8 blobs run two streams per workgroup (two workgroups per CU): waves 2 and 3 run no GRU-B there either, and wave 3
-             * takes a head too (at four streams per workgroup it runs it behind GRU-B's gate stage: 141.7 -> 132 M with both,
-             * but the auto-tune does not pick S = 4 for int8 batches of this size) */
+        dp->eh = (eh && *eh) ? atoi(eh) : (m->is_int8 ? LPCN_DEAL_EH_I8 : LPCN_DEAL_EH_F32);     /* int8: round 3, heads on waves 3..7: 6 / 10 / 14 -> 141 / 145 / 147 M samples/s; round 5: lpcnet_engine.h */
+        {   /* int8 blobs run two streams per workgroup (two workgroups per CU): only two waves run GRU-B there, every other wave takes a
+             * head (a wave that is both -- waves 0, 1 at four streams per workgroup -- runs it behind GRU-B's gate stage; the auto-tune
+             * does not pick S = 4 for int8 batches that fill the GPU) */
             const char *hw = getenv("LPCN_DEAL_HW");
             dp->hw = (hw && *hw) ? atoi(hw) : (m->is_int8 ? LPCN_DEAL_HW_I8 : LPCN_WAVES / 2);
             if (dp->hw < 2) dp->hw = 2;
             if (dp->hw > LPCN_WAVES / 2) dp->hw = LPCN_WAVES / 2;
             if (!m->is_int8) dp->hw = LPCN_WAVES / 2;     /* float kernels re-run a head only on waves that never run GRU-B (a gate wave's parked sums would go stale) */
+            dp->hmask = (0xFFu << dp->hw) & 0xFFu;
+            /* int8 blobs, two streams per workgroup: GRU-B runs on waves LPCN_I8_GBWA / _GBWB (lpcnet_engine.h), every other wave is
+             * free in that phase and may carry a head */
+            const char *hm = getenv("LPCN_DEAL_HMASK");       /* tools */
+            if (m->is_int8 && !for_fast && !(hw && *hw)) dp->hmask = LPCN_DEAL_HMASK_I8;      /* (FAST's own image has no heads and keeps the dealing it was tuned with) */
+            if (m->is_int8 && hm && *hm) dp->hmask = (unsigned)strtoul(hm, NULL, 0) & 0xFFu;
         }
         if (for_fast) {                                /* FAST int8 (GRU-B split over all waves: no shadow to hide a head in): 0 / 6 / 14 -> 184 / 163 / 167 M */
             const char *ehf = getenv("LPCN_DEAL_EH_FAST");
@@ -319,7 +326,7 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
         }
         if (done) {
             /* the lightest GRU-B wave leads the streams (wave 0), the next draws the thresholds (wave 1) */
-            const int nh = dp->tl ? 0 : dp->hw;        /* (waves without a head: interchangeable -- unless the cost model told wave 0 apart) */
+            const int nh = (dp->tl || dp->hmask != ((0xFFu << dp->hw) & 0xFFu)) ? 0 : dp->hw;        /* (waves without a head: interchangeable -- unless the cost model told wave 0 apart) */
             int load4[LPCN_WAVES / 2] = {0}, ord[LPCN_WAVES / 2], newid[LPCN_WAVES];
             for (int sl = 0; sl < NSLOT; sl++) if (w2[sl] < nh) load4[w2[sl]] += slot_max[sl];
             for (int i = 0; i < nh; i++) ord[i] = i;

@@ -374,7 +374,24 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const auto *const emb_exc = as_global(Ap->emb_exc);
 
     // ------------------------------------------------------------------ resident weights ----
-    WT w[NW];
+    // Float blobs denser than 32 items per lane: the first LPCN_NR_F32 items of a lane stay in VGPRs, the others are STREAMED -- re-fetched from
+    // the L2-resident item array every sample, WSD - 1 items ahead of their use, into a ring of WSD registers quads.  (Round 4 kept all 36 / 40
+    // items resident: the allocator then spilled into the sample loop -- 94 scratch accesses per sample at 40 items, 91 M samples/s for a model
+    // with 1.53 x the benchmark model's blocks.  A spilled weight costs the same 1 KB per wave and sample as a streamed one, but its reload sits
+    // right in front of its use.)  Only the waves that own more than NR items ever execute a streamed one.
+#ifndef LPCN_NR_F32
+#define LPCN_NR_F32 28
+#endif
+#ifndef LPCN_WS_DEPTH
+#define LPCN_WS_DEPTH 4
+#endif
+#ifndef LPCN_NR36
+#define LPCN_NR36 LPCN_NR_F32
+#endif
+    constexpr int NR = (!I8 && NW > 32) ? (NW <= 36 ? LPCN_NR36 : LPCN_NR_F32) : NW;      // resident items
+    constexpr int WSD = LPCN_WS_DEPTH;
+    WT w[NR];
+    WT ws[NR < NW ? WSD : 1] = {};
     uint32_t offp[(NW + 1) / 2];
     int row_reg[3];
 #if LPCN_ROW_LDS
@@ -391,11 +408,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         if constexpr (I8) {
             const auto *aq = (const LPCN_GLOBAL int *)as_global(Ap->a_w);
 #pragma unroll
-            for (int j = 0; j < NW; ++j) w[j] = aq[base + (size_t)j * 64];
+            for (int j = 0; j < NR; ++j) w[j] = aq[base + (size_t)j * 64];
         } else {
             const auto *aw = (const LPCN_GLOBAL float *)as_global(Ap->a_w);
 #pragma unroll
-            for (int j = 0; j < NW; ++j) {
+            for (int j = 0; j < NR; ++j) {
                 const auto *v = aw + (base + (size_t)j * 64) * 4;
                 w[j] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -454,6 +471,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         fc_w_s = as_global(Ap->fc_w); fc_b_s = as_global(Ap->fc_b); fc_f_s = as_global(Ap->fc_f);
         asm volatile("" : "+s"(fc_w_s), "+s"(fc_b_s), "+s"(fc_f_s));
     }
+    const LPCN_GLOBAL char *aw_s = (const LPCN_GLOBAL char *)as_global(Ap->a_w);       // item array, for the streamed items (NR < NW)
+    if constexpr (NR < NW) asm volatile("" : "+s"(aw_s));
 #define fc_w_g (HOIST ? fc_w_s : as_global(Ap->fc_w))
 #define fc_b_g (HOIST ? fc_b_s : as_global(Ap->fc_b))
 #define fc_f_g (HOIST ? fc_f_s : as_global(Ap->fc_f))
@@ -791,6 +810,19 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
                 hq[j % (PF + 1)] = *(const HT *)(smem + L::hA + off);
             };
+            auto fetch_w = [&](const int j) {                // streamed item j -> its ring slot (one global_load_dwordx4 per lane: 1 KB per wave, from L2)
+                if constexpr (NR < NW) {
+                    uint32_t wo = (uint32_t)tid0;
+                    LPCN_REMAT_V(wo);                        // (the lane's byte offset is rebuilt from the thread id: no 64-bit per-lane pointer kept across the loop)
+                    wo = (wo >> 6) * (uint32_t)(NW * 1024) + (wo & 63u) * 16u + (uint32_t)j * 1024u;
+                    const LPCN_GLOBAL float *v = (const LPCN_GLOBAL float *)(aw_s + wo);      // ONE scalar base + a 32-bit lane offset (a scalar base per item cost 60 spilled SGPRs at 48 items)
+                    if constexpr (!I8) ws[(j - NR) % WSD] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            };
+            auto wsel = [&](const int j) -> WT {             // item j's weights: resident or from the ring (j is a constant after unrolling)
+                if constexpr (NR < NW) return j < NR ? w[j < NR ? j : 0] : ws[(j >= NR ? j - NR : 0) % WSD];
+                else return w[j];
+            };
             // (LPCN_PARITY_MFMA == 2) the matrix pipe's addend: four registers of -0.0, re-materialised where an item chain starts so
             // that they are not live across the other phases
             typedef float negz_t __attribute__((ext_vector_type(4)));
@@ -842,7 +874,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 } else {
                 const float4 hv = hq[j % (PF + 1)];
                 const float hk[4] = {hv.x, hv.y, hv.z, hv.w};
-                const float wk[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+                const float wk[4] = {wsel(j).x, wsel(j).y, wsel(j).z, wsel(j).w};
                 if constexpr (FAST && S >= 2) {
                     // FAST: the quad broadcast as a 4x4 outer product on the matrix pipe.  v_mfma_f32_4x4x1_16B_f32 gives lane j
                     // of a quad, in register k, A(lane k) * B(lane j) + C: with A = this lane's state value (lane k fetched
@@ -1002,10 +1034,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 constexpr int J0 = NW - LPCN_EARLY_MAX < 0 ? 0 : NW - LPCN_EARLY_MAX;
 #pragma unroll
                 for (int j = 0; j < PF; ++j) if (J0 + j < NW) fetch_h(J0 + j);
+#pragma unroll
+                for (int j = J0; j < J0 + WSD - 1; ++j) if (NR < NW && j >= NR && j < NW) fetch_w(j);
                 auto step = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
                     constexpr int j = decltype(jc)::value;
                     if constexpr (j < NW) {
                         if constexpr (j + PF < NW) fetch_h(j + PF);
+                        if constexpr (NR < NW && j + WSD - 1 >= NR && j + WSD - 1 < NW) fetch_w(j + WSD - 1);
                         if (j >= e0) { asm volatile(""); mac(j); }       // (the empty statement keeps this a scalar branch: if-converted, int8 items became
                                                                         // selects on 24 precomputed lane masks -- 48 SGPRs, most of them spilled)
                         self(self, std::integral_constant<int, j + 1>{});
@@ -1068,6 +1103,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 if (__builtin_expect(j >= jend, 0)) return false;
                 if (j + PF < NW) fetch_h(j + PF);
+                if (NR < NW && j + WSD - 1 >= NR && j + WSD - 1 < NW) fetch_w(j + WSD - 1);
                 // slot boundaries (a slot may be empty: b1 == b2, or b1 == 0): ONE scalar compare per item against the next one
                 // (the rare block drains its own LDS traffic -- s_waitcnt lgkmcnt(0) -- so that the join with the
                 // common path keeps its precise wait counts)
@@ -1372,12 +1408,16 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 return (z0 + z1) + (z2 + z3);
             };
-            const bool gate_wave = gb_split ? (wave % GB_W == 0) : (wave < S);      // wave-uniform
+            // int8 PARITY, S <= 2 (two workgroups per CU): GRU-B's chain waves are LPCN_I8_GBWA (stream 0) and LPCN_I8_GBWB (stream 1) instead of
+            // waves 0 and 1 -- SIMD balance, see lpcnet_engine.h
+            constexpr bool GBMOVE = I8 && !FAST && S <= 2;
+            constexpr int GBWA = GBMOVE ? LPCN_I8_GBWA : 0, GBWB = GBMOVE ? LPCN_I8_GBWB : 1;
+            const bool gate_wave = gb_split ? (wave % GB_W == 0) : (GBMOVE ? (wave == GBWA || (S == 2 && wave == GBWB)) : wave < S);      // wave-uniform
             if constexpr (!I8 && !FAST) {
                 if (gb_scalar) { ++gbseq; if (!gate_wave) mirror_arrive(); }
             }
             float zrh = 0.f, rec = 0.f;
-            const int s = gb_split ? wave / GB_W : wave;     // (stream of a gate wave)
+            const int s = gb_split ? wave / GB_W : (GBMOVE ? (wave == GBWA ? 0 : 1) : wave);     // (stream of a gate wave)
             const int r = lane < RB ? lane : RB - 1;
             if (gb_prod) ++prseq;
             if (gate_wave) {

@@ -57,7 +57,8 @@ static int pick(int nw, int is_int8, int pack2, int grid, int lds, hipStream_t s
     case 30: return launch<30, false, FAST>(grid, lds, st, d_args);
     case 32: return launch<32, false, FAST>(grid, lds, st, d_args);
     case 36: return launch<36, false, FAST>(grid, lds, st, d_args);
-    default: return launch<40, false, FAST>(grid, lds, st, d_args);
+    case 40: return launch<40, false, FAST>(grid, lds, st, d_args);
+    default: return launch<48, false, FAST>(grid, lds, st, d_args);      // (more than 32 items per lane: the items past the 28th are streamed from L2, sample_kernel.hip.h)
     }
 #endif
 }

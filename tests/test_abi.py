@@ -98,14 +98,14 @@ def _layout(blob):
 
 def test_candidate_heads_sit_where_the_kernel_runs_them(blob_f32, blob_i8):
     """the dealing of GRU-A (model_pack.c): the head of a wave's candidate chains is stored end-aligned behind its other items
-    (bound[3] + head <= items per lane); float blobs give heads only to the waves that never run GRU-B (4..7), int8 blobs
-    also to wave 3 (two streams per workgroup is their operating point); waves 0 (leader) and 1 (thresholds) never carry one;
-    a head belongs to a candidate-only first slot."""
-    for blob, first in ((blob_f32, 4), (blob_i8, 3)):
+    (bound[3] + head <= items per lane); float blobs give heads only to the waves that never run GRU-B (4..7); int8 blobs (two
+    streams per workgroup is their operating point) to every wave except GRU-B's chain waves there -- waves 2 and 3 since round 5
+    (lpcnet_engine.h: LPCN_I8_GBWA / _GBWB); a head belongs to a candidate-only first slot."""
+    for blob, headless, headed in ((blob_f32, (0, 1, 2, 3), (4, 5, 6, 7)), (blob_i8, (2, 3), (0, 1, 4, 5, 6, 7))):
         nw, waves = _layout(blob)
         assert 1 <= nw <= 64
         heads = [w["head"] for w in waves]
-        assert all(h == 0 for h in heads[:first]) and all(0 < h <= 24 for h in heads[4:]), heads
+        assert all(heads[w] == 0 for w in headless) and all(0 < heads[w] <= 24 for w in headed), heads
         for w in waves:
             b = w["bound"]
             assert b[0] == 0 and b[0] <= b[1] <= b[2] <= b[3] and b[3] + w["head"] <= nw, (w, nw)

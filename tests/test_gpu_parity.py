@@ -353,16 +353,21 @@ def test_int8_streaming_state_roundtrip(blob_i8, hip_lib):
     dict(grub_density=0.3),                                             # block-sparse GRU-B input matrix (indexed path)
     dict(flavour="int8", densities=(0.07, 0.07, 0.25), grub_density=0.4),
     dict(shaped=False, densities=(0.04, 0.06, 0.15), grub_density=0.6, seed=77),
-], ids=["sparseA", "denseA", "sparseB", "int8-denseA-sparseB", "unshaped"])
+    dict(densities=(0.08, 0.08, 0.3)),                                  # 40 items per lane: items past the 28th are streamed from L2 (round 5), in P1 and in the heads
+    dict(densities=(0.1, 0.1, 0.35)),                                   # 48 items per lane: 1.83 x the benchmark model's blocks (refused before round 5)
+    dict(densities=(0.1, 0.1, 0.35), grub_density=0.5, seed=5),         # ... with the indexed GRU-B path
+], ids=["sparseA", "denseA", "sparseB", "int8-denseA-sparseB", "unshaped", "denseA40-streamed", "denseA48-streamed", "denseA48-sparseB"])
 def test_other_model_shapes_match_oracle(kw, hip_lib):
     """the slot packing, the item-count variants and the GRU-B paths depend on the model: other sparsity patterns"""
     blob = synth.blob_bytes(synth.make_model(**kw))
     rc, info = api.check_model(blob)
     assert rc == 0 and info[5] == 0
+    if kw.get("densities", (0,))[0] >= 0.08:
+        assert info[3] > 32                                              # (the model really needs a streamed variant)
     n, T = 5, 7
     feats = feats_for(range(2300, 2300 + n), T)
     want, states = oracle_run(blob, feats)
-    for S in (1, 4):
+    for S in ((1, 2, 4) if info[3] > 32 else (1, 4)):
         b = api.LPCNetBatch(n, blob)
         b.streams_per_workgroup = S
         got = b.synthesize(feats)

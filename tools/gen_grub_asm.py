@@ -132,9 +132,10 @@ def main_lds(S):
     HR = [base + 8 + 4 * R + 4 * i for i in range(R)]      # state ring
     CNT = 70
     BPT = 16 if 96 % R else (R * (16 // R) if 96 % (R * (16 // R)) == 0 else 12)     # blocks per trip: a multiple of the ring size that divides 96
-    if NBLK % BPT and R == 4: BPT = 8
+    if NBLK % BPT and R == 4 and NBLK % 8 == 0: BPT = 8
     if BPT % R: BPT = {4: 16, 5: 15, 6: 12, 3: 12, 8: 16}.get(R, 16)
-    assert NBLK % BPT == 0 or R == 5
+    TAIL = NBLK % BPT              # blocks behind the last full trip, straight-line (--blocks 86: 5 trips of 16 + 6)
+    assert TAIL == 0 or (R == 4 and TAIL % 2 == 0) or R == 5
     LA = R - 1
     lines = []
     rdw = lambda slot, blk: f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}"
@@ -160,8 +161,13 @@ def main_lds(S):
               f"v_add_u32 %[hp], {ha_off(BPT)}, %[hp]",
               f"s_sub_u32 s{CNT}, s{CNT}, 1",
               f"s_cmp_lg_u32 s{CNT}, 0",
-              "s_cbranch_scc1 1b",
-              "s_waitcnt lgkmcnt(0)"]
+              "s_cbranch_scc1 1b"]
+    for k in range(TAIL if R == 4 else 0):     # (the pointers have been advanced: the tail's offsets start over; it reads LA blocks past its end like the last trip)
+        pr = prod((k + 1) & 1, (k + 1) % R)
+        a = [f"v_add_f32 %[z], %[z], v{PS[k & 1] + j}" for j in range(4)]
+        lines += [rdw((k + LA) % R, k + LA), rdh((k + LA) % R, k + LA), f"s_waitcnt lgkmcnt({2 * (LA - 1)})",
+                  a[0], pr[0], a[1], pr[1], a[2], a[3]]
+    lines += ["s_waitcnt lgkmcnt(0)"]
     if MASK48:
         lines += ["s_mov_b64 exec, s[72:73]"]
     print("// generated by tools/gen_grub_asm.py --lds %d -- do not edit" % S)

@@ -18,10 +18,10 @@ from lpcnet_amd import synth  # noqa: E402
 T = 1000
 
 
-def run(exe, flavour, repeat=3):
+def run(exe, flavour, repeat=3, frames=T):
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "weights_blob.bin"), "wb").write(synth.blob_bytes(synth.make_model(flavour=flavour)))
-        synth.make_features(1000, T).astype(np.float32).tofile(os.path.join(d, "feat.f32"))
+        synth.make_features(1000, T)[:frames].astype(np.float32).tofile(os.path.join(d, "feat.f32"))
         best = None
         for _ in range(repeat):
             t0 = time.perf_counter()
@@ -41,6 +41,12 @@ def main():
             continue
         s = run(path, flavour)
         out[name] = {"seconds": round(s, 3), "real_time_factor": round(T / 100.0 / s, 2)}
+        # the split: the same program on the first 20 frames -- the difference is 980 frames of steady state,
+        # what is left of the short run is process start + HIP initialisation + model packing and upload
+        s20 = run(path, flavour, frames=20)
+        per_frame = (s - s20) / (T - 20)
+        out[name].update({"seconds_20_frames": round(s20, 3), "ms_per_frame_steady": round(per_frame * 1e3, 4), "startup_seconds": round(s20 - 20 * per_frame, 3),
+                          "real_time_factor_steady": round(0.01 / per_frame, 2)})
     print(json.dumps(out, indent=1))
 
 
