@@ -134,6 +134,12 @@ template <typename T> __device__ __forceinline__ LPCN_GLOBAL T *as_global_rw(T *
 #ifndef LPCN_PROD_BLOCKS
 #define LPCN_PROD_BLOCKS 48
 #endif
+#ifndef LPCN_GRUB_RING
+#define LPCN_GRUB_RING 0        // 1 / 2: four float streams per workgroup -- waves 4..7 form the products of GRU-B's last 10 blocks of their partner stream before / after their
+                                // candidate heads (see Lds<S>::RING_BLOCKS).  MEASURED AND NOT KEPT (round 5): bit-exact, 125.6 (before) / 121.5 (after) vs 126.8 M
+                                // samples/s -- the ten blocks cost the producer 1.9 k clk (not 0.5 k) and the chain wave's GRU-B gets 0.2 k LONGER: the phase is bound by what the four
+                                // chain waves + four head waves already ask of the LDS pipe, and products through LDS are one more KB written and read per block (EXPERIMENTS.md)
+#endif
 template <int S> struct Lds {
     static constexpr int HA_STRIDE = 16 * S;                       // bytes per 4-neuron block
     static constexpr int hA     = 0;
@@ -169,7 +175,11 @@ template <int S> struct Lds {
     // ([block][48 rows] float4, 768 B per block) -- the chain then costs one read + four adds per block instead of two reads, two
     // packed multiplies and four adds.  Only S = 1 has the room (50 KB free of the 160 KB).
     static constexpr int PROD_BLOCKS = LPCN_PROD_BLOCKS, PROD_FIRST = 96 - PROD_BLOCKS;      // (the two assembly loops are generated for this split)
-    static constexpr int prod_sz = S == 1 ? (PROD_BLOCKS + 7) * RB * 16 : 0;      // (+ 7 blocks: the chain wave's ring of eight reads ahead past the last block on its last trip)
+    // four streams per workgroup (round 5): a RING of products for GRU-B's last RING_BLOCKS blocks of every stream, formed by waves 4..7 before their
+    // candidate heads.  10 blocks x 4 streams x 768 B = 30.7 KB live in cells that are dead while GRU-B runs -- the update / reset pre-activations
+    // (RING_SEG0 = 4 blocks per stream), the candidate inputs (RING_SEG1 = 2) -- and in the 12 KB that were free (RING_SEG2 = 4: `prod`).
+    static constexpr int RING_BLOCKS = 10, RING_FIRST = 96 - RING_BLOCKS, RING_SEG0 = 4, RING_SEG1 = 2, RING_SEG2 = 4;
+    static constexpr int prod_sz = S == 1 ? (PROD_BLOCKS + 7) * RB * 16 : (S == 4 && LPCN_GRUB_RING ? S * RING_SEG2 * RB * 16 : 0);      // (S = 1, + 7 blocks: the chain wave's ring of eight reads ahead past the last block on its last trip)
     static constexpr int prod(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }
     static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? 0 : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #ifndef LPCN_NR36
 #define LPCN_NR36 LPCN_NR_F32
 #endif
-    constexpr int NR = (!I8 && NW > 32) ? (NW <= 36 ? LPCN_NR36 : LPCN_NR_F32) : NW;      // resident items
+    constexpr int NR = (!I8 && NW > (LPCN_GRUB_RING ? 30 : 32)) ? (NW <= 36 ? LPCN_NR36 : LPCN_NR_F32) : NW;      // resident items (a build with GRU-B's product ring streams at 32 items already)
     constexpr int WSD = LPCN_WS_DEPTH;
     WT w[NR];
     WT ws[NR < NW ? WSD : 1] = {};
@@ -450,6 +460,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #define LPCN_GRUB_PROD 1        // 1: single stream per workgroup -- waves 1..3 form the products of GRU-B's last 64 blocks for the chain wave
 #endif
     const bool gb_prod = LPCN_GRUB_PROD && S == 1 && gb_lds;
+    const bool gb_ring = LPCN_GRUB_RING && S == 4 && gb_lds;
     // Argument-block members the sample loop needs on its critical path, fetched ONCE and made opaque: left to itself the
     // compiler re-reads them with a scalar load at every use (cheaper than keeping an SGPR, it thinks), and a scalar load in
     // flight forces every LDS wait behind it to lgkmcnt(0) -- right behind a barrier that is a stall for every wave (int8:
@@ -693,7 +704,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     };
     auto prod_wait = [&]() {
         int v;
-        const int want = prseq * 3;
+        const int want = prseq * (S == 4 ? 4 : 3);          // (producers: waves 1..3 of a single-stream workgroup, waves 4..7 of a four-stream one)
         do {
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(prod_cnt_addr) : "memory");
             v = __builtin_amdgcn_readfirstlane(v);
@@ -1419,7 +1430,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             float zrh = 0.f, rec = 0.f;
             const int s = gb_split ? wave / GB_W : (GBMOVE ? (wave == GBWA ? 0 : 1) : wave);     // (stream of a gate wave)
             const int r = lane < RB ? lane : RB - 1;
-            if (gb_prod) ++prseq;
+            if (gb_prod || gb_ring) ++prseq;
             if (gate_wave) {
                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
                 __builtin_amdgcn_s_setprio(3);                 // (priority 1 or none: the same step time, measured)
@@ -1505,9 +1516,30 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                             // 128-VGPR variants (two workgroups per CU): the other workgroup hides the LDS latency, a
                             // two-quad pipeline is enough and keeps the kernel out of scratch memory
 #ifndef LPCN_I8_GB_DEPTH
-#define LPCN_I8_GB_DEPTH 2
+#define LPCN_I8_GB_DEPTH 3      // quads of GRU-B's ring on the 128-VGPR kernels: 2 / 3 / 4 -> 169.2 / 172.0 / see EXPERIMENTS.md M samples/s (round 5, chain waves 2, 3; round 4, chain waves 0, 1: 2 and 3 equal)
 #endif
-                            if constexpr (LPCN_I8_GB_DEPTH == 3) {     // reads two quads ahead
+#ifndef LPCN_I8_GB_ASM
+#define LPCN_I8_GB_ASM 0
+#endif
+                            if constexpr (LPCN_I8_GB_ASM) {
+                                // the hand-scheduled form of this loop (tools/gen_grub_asm.py --i8 96 --ring 3): the dots and conversions of quad q + 1 in the
+                                // shadow of the four dependent adds of quad q, reads two quads ahead; v96..v127 are named by the block
+                                uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(const unsigned char *)wq;
+                                uint32_t xp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(const unsigned char *)xq4;
+                                asm volatile(
+#include "grub_i8_loop.inc"
+                                    : [z] "+v"(zrh), [wp] "+v"(wp32), [xp] "+v"(xp32) : : LPCN_GRUB_I8_CLOBBERS_96);
+                            } else if constexpr (LPCN_I8_GB_DEPTH == 4) {     // reads three quads ahead
+                                i4 w0 = wq[0], x0 = xq4[0], w1 = wq[8], x1 = xq4[1], w2 = wq[16], x2 = xq4[2];
+#pragma unroll 4
+                                for (int q = 0; q < 24; ++q) {
+                                    const i4 w3 = wq[(q + 3) * 8], x3 = xq4[q + 3];     // (past the end on the last trips: padded / unused)
+                                    float d[4];
+                                    dot4_cvt_x4(d, w0[0], w0[1], w0[2], w0[3], x0[0], x0[1], x0[2], x0[3]);
+                                    zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3];
+                                    w0 = w1; x0 = x1; w1 = w2; x1 = x2; w2 = w3; x2 = x3;
+                                }
+                            } else if constexpr (LPCN_I8_GB_DEPTH == 3) {     // reads two quads ahead
                                 i4 w0 = wq[0], x0 = xq4[0], w1 = wq[8], x1 = xq4[1];
 #pragma unroll 3
                                 for (int q = 0; q < 24; ++q) {
@@ -1583,9 +1615,23 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::bw + (sm_bstart[g] * 8 + ri) * 16 + ((0x321100 >> (4 * g)) & 15) * 128);
                     uint32_t hp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::hA + s * 16);
                     if constexpr (S == 4) {
+                      if (gb_ring) {
+                        // blocks 0 .. RING_FIRST - 1 as below, then the products that wave 4 + s has left in the ring
+                        asm volatile(
+#include "grub_lds_loop_s4_first.inc"
+                            : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS4F_CLOBBERS);
+                        prod_wait();
+                        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+                        uint32_t q0 = lds0 + L::pre + (s * L::RING_SEG0 * RB + r) * 16, q1 = lds0 + L::inh + (s * L::RING_SEG1 * RB + r) * 16;
+                        uint32_t q2 = lds0 + L::prod(Ap->nb_b, I8) + (s * L::RING_SEG2 * RB + r) * 16;
+                        asm volatile(
+#include "grub_ring_sum.inc"
+                            : [z] "+v"(zrh) : [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2) : LPCN_GRUB_RING_SUM_CLOBBERS);
+                      } else {
                         asm volatile(
 #include "grub_lds_loop_s4.inc"
                             : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
+                      }
                     } else if constexpr (S == 2) {
                         asm volatile(
 #include "grub_lds_loop_s2.inc"
@@ -1704,6 +1750,24 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 prod_arrive();
+            } else if (gb_ring) {
+                // ---- four streams: wave 4 + s multiplies weight x state for the last RING_BLOCKS blocks of stream s and leaves the products in the ring
+                // (the same single multiply per term as the chain wave's own v_pk_mul_f32), then runs its candidate heads
+                if (LPCN_GRUB_RING == 2 && early_wave) run_head();      // (2: the products AFTER the heads, in the time the wave would otherwise wait for GRU-B)
+                if constexpr (S == 4) {
+                    const int ps = wave - LPCN_WAVES / 2;          // (every non-gate wave of a four-stream workgroup is one of 4..7)
+                    const int g = r >> 3, ri = r & 7;
+                    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+                    const uint32_t wp32 = lds0 + L::bw + (sm_bstart[g] * 8 + ri) * 16 + ((0x321100 >> (4 * g)) & 15) * 128;
+                    const uint32_t hp32 = lds0 + L::hA + ps * 16;
+                    const uint32_t q0 = lds0 + L::pre + (ps * L::RING_SEG0 * RB + r) * 16, q1 = lds0 + L::inh + (ps * L::RING_SEG1 * RB + r) * 16;
+                    const uint32_t q2 = lds0 + L::prod(Ap->nb_b, I8) + (ps * L::RING_SEG2 * RB + r) * 16;
+                    asm volatile(
+#include "grub_ring_fill.inc"
+                        : : [wp] "v"(wp32), [hp] "v"(hp32), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2) : LPCN_GRUB_RING_FILL_CLOBBERS);
+                    prod_arrive();
+                }
+                if (LPCN_GRUB_RING != 2 && early_wave) run_head();
             } else if (early_wave) {
                 // ---- the head of the next sample's candidate chains (runs in the shadow of GRU-B)
                 run_head();

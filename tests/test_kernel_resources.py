@@ -87,7 +87,12 @@ def test_generated_assembly_loops_are_what_the_generator_emits():
     assert (prod + 7) * 48 * 16 + 113392 - 6144 <= 160 * 1024      # the products (+ the 7 blocks the chain wave's ring reads ahead) + the rest of the single-stream carve-up (107 248 B since the unused row table went) fit the CU's LDS
     cases = [(["--lds", "1"], "grub_lds_loop_s1.inc"), (["--lds", "2"], "grub_lds_loop_s2.inc"), (["--lds", "4"], "grub_lds_loop_s4.inc"),
              (["--lds", "1", "--blocks", str(96 - prod), "--name", "LPCN_GRUB_LDS32_CLOBBERS"], "grub_lds_loop_s1_first.inc"),
-             (["--prod", str(prod)], "grub_prod_loop.inc"), ([], "grub_scalar_loop.inc")]
+             (["--prod", str(prod)], "grub_prod_loop.inc"), ([], "grub_scalar_loop.inc"),
+             # round 5, four streams per workgroup: the chain wave's first 86 blocks, the ring's producer and consumer sides (Lds<4>::RING_BLOCKS = 10)
+             (["--lds", "4", "--blocks", "86", "--name", "LPCN_GRUB_LDS4F_CLOBBERS"], "grub_lds_loop_s4_first.inc"),
+             (["--ring-fill", "4"], "grub_ring_fill.inc"), (["--ring-sum"], "grub_ring_sum.inc")]
+    kh = open(os.path.join(csrc, "sample_kernel.hip.h")).read()
+    assert "RING_BLOCKS = 10, RING_FIRST = 96 - RING_BLOCKS, RING_SEG0 = 4, RING_SEG1 = 2, RING_SEG2 = 4" in kh      # = the generator's RING_SEG and --first 86
     for args, name in cases:
         out = subprocess.run([sys.executable, gen] + args, capture_output=True, text=True, check=True).stdout
         assert out == open(os.path.join(csrc, name)).read(), name

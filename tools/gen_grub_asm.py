@@ -284,6 +284,84 @@ def main_prod(nblk):
         print('"%s\\n\\t"' % ln)
 
 
+RING_SEG = (4, 2, 4)     # blocks of a stream's product ring per LDS region (update/reset pre-activations, candidate inputs, free tail)
+
+
+def main_ring_fill(S, first):
+    """S = 4, float PARITY: the PRODUCER side of GRU-B's product ring.  Wave 4 + s (idle until its candidate heads start) multiplies
+    weight x state for blocks first..95 of stream s -- one row per lane, the same two 16-byte reads per block as the chain wave's loop
+    -- and stores the four products of (row, block) where the chain wave picks them up (main_ring_sum).  The ring lives in cells that
+    are dead while GRU-B runs: the update / reset pre-activations (4 blocks per stream), the candidate inputs (2) and the free tail (4).
+    Uses the chain loop's register block (v216..v255 are reserved by it anyway): ring of four blocks, products formed in place."""
+    stride = 16 * S
+    ha_off = lambda p: p * stride + (p >> 2) * 16
+    n = 96 - first
+    assert sum(RING_SEG) == n
+    R = 4
+    base = 256 - 8 * R
+    WR = [base + 4 * i for i in range(R)]
+    HR = [base + 4 * R + 4 * i for i in range(R)]
+    seg_of = []
+    for si, cnt in enumerate(RING_SEG):
+        seg_of += [(si, k) for k in range(cnt)]
+    rdw = lambda b: f"ds_read_b128 v[{WR[b % R]}:{WR[b % R] + 3}], %[wp] offset:{(first + b) * 128}"
+    rdh = lambda b: f"ds_read_b128 v[{HR[b % R]}:{HR[b % R] + 3}], %[hp] offset:{ha_off(first + b)}"
+    def body(b):
+        si, k = seg_of[b]
+        return [f"v_pk_mul_f32 v[{HR[b % R]}:{HR[b % R] + 1}], v[{HR[b % R]}:{HR[b % R] + 1}], v[{WR[b % R]}:{WR[b % R] + 1}]",
+                f"v_pk_mul_f32 v[{HR[b % R] + 2}:{HR[b % R] + 3}], v[{HR[b % R] + 2}:{HR[b % R] + 3}], v[{WR[b % R] + 2}:{WR[b % R] + 3}]",
+                f"ds_write_b128 %[q{si}], v[{HR[b % R]}:{HR[b % R] + 3}] offset:{k * 768}"]
+    lines = ["s_waitcnt lgkmcnt(0)"]
+    queue = []                                     # LDS operations issued so far, in order (they complete in order): ("r", block) / ("w", block)
+    def issue(kind, b, text):
+        queue.append((kind, b))
+        lines.append(text)
+    for b in range(R - 1):
+        issue("r", b, rdw(b)); issue("r", b, rdh(b))
+    for b in range(n):
+        if b + R - 1 < n:
+            # (slot (b + R - 1) % R was stored from by block b - 1: that ds_write has been issued, and its data left the registers long before
+            # a read's data can come back)
+            issue("r", b + R - 1, rdw(b + R - 1)); issue("r", b + R - 1, rdh(b + R - 1))
+        last = max(i for i, (kind, blk) in enumerate(queue) if kind == "r" and blk == b)
+        lines.append(f"s_waitcnt lgkmcnt({len(queue) - 1 - last})")      # everything issued after block b's second read may still be out
+        m = body(b)
+        lines += m[:2]
+        issue("w", b, m[2])
+    print("// generated by tools/gen_grub_asm.py --ring-fill %d --first %d -- do not edit" % (S, first))
+    print("// operands: %[wp] LDS byte address of the lane's row, block 0; %[hp] LDS byte address of the stream's state, block 0; %[q0] %[q1] %[q2] LDS byte addresses of the lane's row in the ring's three regions")
+    clob = [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_RING_FILL_CLOBBERS")
+    print("#define LPCN_GRUB_RING_FILL_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
+def main_ring_sum(first):
+    """The CONSUMER side: the chain wave has summed blocks 0..first-1 itself (--lds 4 --blocks first); the products of the others wait in
+    the ring.  Per block ONE ds_read_b128 and the four dependent v_add_f32; all reads of the ten blocks are issued up front (40 VGPRs)."""
+    n = 96 - first
+    assert sum(RING_SEG) == n
+    base = 256 - 4 * n
+    RG = [base + 4 * i for i in range(n)]
+    seg_of = []
+    for si, cnt in enumerate(RING_SEG):
+        seg_of += [(si, k) for k in range(cnt)]
+    lines = ["s_waitcnt lgkmcnt(0)"]
+    for b in range(n):
+        si, k = seg_of[b]
+        lines += [f"ds_read_b128 v[{RG[b]}:{RG[b] + 3}], %[q{si}] offset:{k * 768}"]
+    for b in range(n):
+        lines += [f"s_waitcnt lgkmcnt({n - 1 - b})"] + [f"v_add_f32 %[z], %[z], v{RG[b] + j}" for j in range(4)]
+    print("// generated by tools/gen_grub_asm.py --ring-sum --first %d -- do not edit" % first)
+    print("// operands: %[z] float accumulator (in/out VGPR); %[q0] %[q1] %[q2] LDS byte addresses of the lane's row in the ring's three regions")
+    clob = [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_RING_SUM_CLOBBERS")
+    print("#define LPCN_GRUB_RING_SUM_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
 def main_dpp(S):
     """GRU-B input mat-vec with ONE state read per FOUR blocks: lane k of a quad (four consecutive rows: same stream, same row
     group) fetches block 4q + k of the wave's stream, and the four rows take each block's values through quad broadcasts folded
@@ -360,7 +438,7 @@ def main_i8(base):
     rdx = lambda q: f"ds_read_b128 v[{XR[q % R]}:{XR[q % R] + 3}], %[xp] offset:{q * 16}"
     dots = lambda q: [f"v_dot4_i32_i8 v{D + k}, v{WR[q % R] + k}, v{XR[q % R] + k}, 0" for k in range(4)]
     cvts = [f"v_cvt_f32_i32 v{F + k}, v{D + k}" for k in range(4)]
-    lines = [f"s_mov_b32 s{CNT}, {NQ // R}"]
+    lines = ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{CNT}, {NQ // R}"]      # (entry: see --lds)
     for q in range(LA):
         lines += [rdw(q), rdx(q)]
     lines += [f"s_waitcnt lgkmcnt({2 * (LA - 1)})"] + dots(0) + cvts
@@ -388,7 +466,12 @@ def main_i8(base):
 
 
 if __name__ == "__main__":
-    if "--i8" in sys.argv:
+    FIRST = int(sys.argv[sys.argv.index("--first") + 1]) if "--first" in sys.argv else 86
+    if "--ring-fill" in sys.argv:
+        main_ring_fill(int(sys.argv[sys.argv.index("--ring-fill") + 1]), FIRST)
+    elif "--ring-sum" in sys.argv:
+        main_ring_sum(FIRST)
+    elif "--i8" in sys.argv:
         main_i8(int(sys.argv[sys.argv.index("--i8") + 1]))
     elif "--dpp" in sys.argv:
         main_dpp(int(sys.argv[sys.argv.index("--dpp") + 1]))

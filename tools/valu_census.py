@@ -164,7 +164,7 @@ def main_int8(a):
     # ---- P2
     c2 = count(R["P2"])
     add("P2", "gate stage: 768 (neuron, stream) items on 512 lanes = 2 rounds (the second half empty), 2 sigmoid + 1 tanh (table) each, blend, re-quantisation floor(.5 + 127 x) in double, byte stores", c2, 8, "straight-line")
-    # ---- P3: GRU-B's quad loop on waves 0..1, heads on waves 3..7, the rest
+    # ---- P3: GRU-B's quad loop on the two chain waves (2, 3 since round 5), heads on the six others, the rest
     loops = [(s0, e0) for s0, e0 in inner_loops(R["P3"]) if any("v_dot4" in ln for ln in R["P3"][s0:e0])]
     gb = zero
     gb_lines = set()
@@ -183,7 +183,7 @@ def main_int8(a):
     it3["mfma"] = 1
     add("P3", "candidate HEAD item (same body as P1's)", it3, n_head, f"{n_head} wave-items per step ({'; '.join(str(w['head']) for w in waves)} per wave)")
     rest3 = sub(count(p3), it3, len(idx3))
-    add("P3", "recurrent part + GRU-B gates + re-quantisation (gate waves 0, 1), head start values (waves 3..7), dual-FC row prefetch (all) (static count / 2: gate and head waves run different halves)",
+    add("P3", "recurrent part + GRU-B gates + re-quantisation (chain waves 2, 3), head start values (the six other waves), dual-FC row prefetch (all) (static count / 2: gate and head waves run different halves)",
         {k: max(v, 0) / 2 for k, v in rest3.items()}, 8, f"static: {rest3['valu']} VALU outside the {len(idx3)} head item bodies and the quad loop")
     add("P4", "tree: 255 nodes x 2 channels x 2 streams speculatively (16 mul + 16 add + table tanh per stream and lane), ballots", count(R["P4"]), 8, "straight-line")
     add("P5", "leader (wave 0): tree walk, mu-law, LPC chain, publish; thresholds (wave 1)", count(R["P5"]), 1, "straight-line, one wave")
