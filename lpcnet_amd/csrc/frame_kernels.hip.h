@@ -32,6 +32,25 @@ struct LpcnFrameModel {
 namespace lpcn {
 
 constexpr int FT = 8;            // frames per tile (weight reuse factor)
+#ifndef LPCN_FRAME_UNROLL
+#define LPCN_FRAME_UNROLL 16     // trips of a weight loop unrolled together in the one-frame kernels: that many L2 loads of a lane in flight (the sums keep their order)
+#endif
+#ifndef LPCN_FRAME_UNROLL_F1
+#define LPCN_FRAME_UNROLL_F1 1   // ... in the chunk kernel (FT frames of one stream per tile: throughput-bound, the hint costs it 0.3 ms per 25-frame step)
+#endif
+#ifndef LPCN_FRAME_UNROLL_PJ8
+#define LPCN_FRAME_UNROLL_PJ8 1  // ... in the projection kernel with full tiles
+#endif
+#define LPCN_STR2(x) #x
+#define LPCN_STR(x) LPCN_STR2(x)
+#if LPCN_FRAME_UNROLL_F1 > 1
+#define LPCN_PRAGMA_F1 _Pragma(LPCN_STR(unroll LPCN_FRAME_UNROLL_F1))
+#else
+#define LPCN_PRAGMA_F1           /* (the compiler's own choice, as before round 5) */
+#endif
+#ifndef LPCN_PROJ_SPLIT_MAX
+#define LPCN_PROJ_SPLIT_MAX 2048 // (stream, frame) items up to which the projection's ten row blocks are separate workgroups
+#endif
 constexpr int FIN = LPCN_FRAME_IN, CN = LPCN_COND;
 
 // ---------------------------------------------------------------------------------------------
@@ -87,6 +106,7 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
         // conv1: out[t] = b + sum_j W[j][i] * window_t[j], window_t = x1[t*FIN .. t*FIN+3*FIN)
 #pragma unroll
         for (int t = 0; t < FT; ++t) acc[t] = M.conv1_b[i];
+        LPCN_PRAGMA_F1
         for (int j = 0; j < 3 * FIN; ++j) {
             const float wv = M.conv1_w[j * CN + i];
 #pragma unroll
@@ -103,6 +123,7 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
         // conv2
 #pragma unroll
         for (int t = 0; t < FT; ++t) acc[t] = M.conv2_b[i];
+        LPCN_PRAGMA_F1
         for (int j = 0; j < 3 * CN; ++j) {
             const float wv = M.conv2_w[j * CN + i];
 #pragma unroll
@@ -119,6 +140,7 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
         // dense1
 #pragma unroll
         for (int t = 0; t < FT; ++t) acc[t] = M.dense1_b[i];
+        LPCN_PRAGMA_F1
         for (int j = 0; j < CN; ++j) {
             const float wv = M.dense1_w[j * CN + i];
 #pragma unroll
@@ -131,6 +153,7 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
         // dense2
 #pragma unroll
         for (int t = 0; t < FT; ++t) acc[t] = M.dense2_b[i];
+        LPCN_PRAGMA_F1
         for (int j = 0; j < CN; ++j) {
             const float wv = M.dense2_w[j * CN + i];
 #pragma unroll
@@ -165,8 +188,12 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
 // throws 7 of its 8 accumulators away: 0.81 ms for 8 192 streams (8 % of the 10-ms step), L2-bandwidth bound.  Same arithmetic per
 // output (inputs in ascending order, multiply and add rounded separately): bit-identical to F1.
 // ---------------------------------------------------------------------------------------------
-constexpr int ST = 8;            // streams per tile
-
+constexpr int ST_MAX = 8;        // streams per tile of a full batch
+// (round 5: ST is a template parameter -- a batch of one to four streams, i.e. every call of the reference's per-frame API that finds no
+// company in the combining dispatcher, ran eight accumulators for one stream: 58 us per frame for a single stream, instruction-bound on
+// two waves; and the weight loops carry an unroll hint so that a lane has LPCN_FRAME_UNROLL L2 loads in flight instead of one per
+// trip -- rocprofv3 on the reference's demo: frame_cond 57.7 -> see EXPERIMENTS.md us, frame_proj 75.6 -> us per frame)
+template <int ST>
 __global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, int n_streams, const float *feat, size_t feat_stream_stride,
                                                             lpcn_stream_state *states, int *fc_base, float *cond_out /*[stream][128]*/,
                                                             float *lpc_out /*[stream][16]*/)
@@ -219,6 +246,7 @@ __global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, in
     float acc[ST];
 #pragma unroll
     for (int t = 0; t < ST; ++t) acc[t] = M.conv1_b[i];
+#pragma unroll LPCN_FRAME_UNROLL
     for (int j = 0; j < 3 * FIN; ++j) {
         const float wv = M.conv1_w[j * CN + i];
 #pragma unroll
@@ -233,6 +261,7 @@ __global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, in
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < ST; ++t) acc[t] = M.conv2_b[i];
+#pragma unroll LPCN_FRAME_UNROLL
     for (int j = 0; j < 3 * CN; ++j) {
         const float wv = M.conv2_w[j * CN + i];
 #pragma unroll
@@ -247,6 +276,7 @@ __global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, in
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < ST; ++t) acc[t] = M.dense1_b[i];
+#pragma unroll LPCN_FRAME_UNROLL
     for (int j = 0; j < CN; ++j) {
         const float wv = M.dense1_w[j * CN + i];
 #pragma unroll
@@ -258,6 +288,7 @@ __global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, in
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < ST; ++t) acc[t] = M.dense2_b[i];
+#pragma unroll LPCN_FRAME_UNROLL
     for (int j = 0; j < CN; ++j) {
         const float wv = M.dense2_w[j * CN + i];
 #pragma unroll
@@ -281,43 +312,69 @@ __global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, in
 // three arrays are dense in it -- so a tile is full whatever the number of frames per stream (round 5: with one frame per stream,
 // the real-time case, a tile per stream used one accumulator of eight).  Lane = output column.
 // ---------------------------------------------------------------------------------------------
+// (round 5: for small batches the nine 128-row blocks of the GRU-A conditioning and the GRU-B conditioning are blockIdx.y = 0..9 -- one
+// workgroup walked all ten in turn, 76 us for a single (stream, frame) item; and the tile size is a template parameter, see frame_cond_t1_kernel)
+template <int FTT>
 __global__ __launch_bounds__(128) void frame_proj_kernel(LpcnFrameModel M, size_t n_items, const float *cond,
                                                          float *cond_a, float *cond_b)
 {
-    __shared__ float c[FT * CN];
+    __shared__ float c[FTT * CN];
     const int i = threadIdx.x;
-    const size_t item0 = (size_t)blockIdx.x * FT;
-    const int nt = n_items - item0 < (size_t)FT ? (int)(n_items - item0) : FT;
-    for (int k = i; k < FT * CN; k += 128) {
+    const size_t item0 = (size_t)blockIdx.x * FTT;
+    const int nt = n_items - item0 < (size_t)FTT ? (int)(n_items - item0) : FTT;
+    for (int k = i; k < FTT * CN; k += 128) {
         const int t = k / CN;
         c[k] = t < nt ? cond[(item0 + t) * CN + k % CN] : 0.f;
     }
     __syncthreads();
-    float acc[FT];
-    for (int rb = 0; rb < LPCN_ROWS_A / 128; ++rb) {
-        const int r = rb * 128 + i;
+    float acc[FTT];
+    constexpr int NRB = LPCN_ROWS_A / 128;             // row blocks of the GRU-A conditioning; block NRB = the GRU-B conditioning
+    constexpr int UNR = FTT == FT ? LPCN_FRAME_UNROLL_PJ8 : LPCN_FRAME_UNROLL;
+    // gridDim.y == NRB + 1: one row block per workgroup (few items: latency matters); gridDim.y == 1: this workgroup walks all of them
+    const int rb0 = gridDim.y > 1 ? blockIdx.y : 0, rb1 = gridDim.y > 1 ? blockIdx.y + 1 : NRB + 1;
+    for (int rb = rb0; rb < rb1; ++rb) {
+        if (rb < NRB) {
+            const int r = rb * 128 + i;
 #pragma unroll
-        for (int t = 0; t < FT; ++t) acc[t] = M.a_dense_b[r];
-        for (int j = 0; j < CN; ++j) {
-            const float wv = M.a_dense_w[j * LPCN_ROWS_A + r];
+            for (int t = 0; t < FTT; ++t) acc[t] = M.a_dense_b[r];
+            if constexpr (UNR > 1) {
+#pragma unroll UNR
+                for (int j = 0; j < CN; ++j) {
+                    const float wv = M.a_dense_w[j * LPCN_ROWS_A + r];
 #pragma unroll
-            for (int t = 0; t < FT; ++t) acc[t] = acc[t] + wv * c[t * CN + j];
+                    for (int t = 0; t < FTT; ++t) acc[t] = acc[t] + wv * c[t * CN + j];
+                }
+            } else {
+                for (int j = 0; j < CN; ++j) {
+                    const float wv = M.a_dense_w[j * LPCN_ROWS_A + r];
+#pragma unroll
+                    for (int t = 0; t < FTT; ++t) acc[t] = acc[t] + wv * c[t * CN + j];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < FTT; ++t)
+                if (t < nt) cond_a[(item0 + t) * LPCN_ROWS_A + r] = acc[t];
+        } else if (i < LPCN_ROWS_B) {
+#pragma unroll
+            for (int t = 0; t < FTT; ++t) acc[t] = M.b_dense_b[i];
+            if constexpr (UNR > 1) {
+#pragma unroll UNR
+                for (int j = 0; j < CN; ++j) {
+                    const float wv = M.b_dense_w[j * LPCN_ROWS_B + i];
+#pragma unroll
+                    for (int t = 0; t < FTT; ++t) acc[t] = acc[t] + wv * c[t * CN + j];
+                }
+            } else {
+                for (int j = 0; j < CN; ++j) {
+                    const float wv = M.b_dense_w[j * LPCN_ROWS_B + i];
+#pragma unroll
+                    for (int t = 0; t < FTT; ++t) acc[t] = acc[t] + wv * c[t * CN + j];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < FTT; ++t)
+                if (t < nt) cond_b[(item0 + t) * LPCN_ROWS_B + i] = acc[t];
         }
-#pragma unroll
-        for (int t = 0; t < FT; ++t)
-            if (t < nt) cond_a[(item0 + t) * LPCN_ROWS_A + r] = acc[t];
-    }
-    if (i < LPCN_ROWS_B) {
-#pragma unroll
-        for (int t = 0; t < FT; ++t) acc[t] = M.b_dense_b[i];
-        for (int j = 0; j < CN; ++j) {
-            const float wv = M.b_dense_w[j * LPCN_ROWS_B + i];
-#pragma unroll
-            for (int t = 0; t < FT; ++t) acc[t] = acc[t] + wv * c[t * CN + j];
-        }
-#pragma unroll
-        for (int t = 0; t < FT; ++t)
-            if (t < nt) cond_b[(item0 + t) * LPCN_ROWS_B + i] = acc[t];
     }
 }
 
@@ -515,13 +572,18 @@ static inline int lpcn_launch_frame_kernels(const LpcnFrameModel &M, hipStream_t
                                             float *d_cond, float *d_cond_a, float *d_cond_b, float *d_lpc, char *err, size_t errlen)
 {
     const size_t items = (size_t)n * n_frames;
-    if (n_frames == 1)       // one frame per stream (real-time steps, the legacy API's passes): tiles of ST streams
-        hipLaunchKernelGGL(lpcn::frame_cond_t1_kernel, dim3((n + lpcn::ST - 1) / lpcn::ST), dim3(128), 0, st, M, n, d_feat, feat_stream_stride,
-                           d_state, d_fc_base, d_cond, d_lpc);
-    else
+    if (n_frames == 1) {     // one frame per stream (real-time steps, the legacy API's passes): tiles of up to 8 streams
+#define LPCN_T1(STV) hipLaunchKernelGGL(lpcn::frame_cond_t1_kernel<STV>, dim3((n + STV - 1) / STV), dim3(128), 0, st, M, n, d_feat, feat_stream_stride, d_state, d_fc_base, d_cond, d_lpc)
+        if (n >= 8 || n > 4) LPCN_T1(8); else if (n > 2) LPCN_T1(4); else if (n == 2) LPCN_T1(2); else LPCN_T1(1);
+#undef LPCN_T1
+    } else
         hipLaunchKernelGGL(lpcn::frame_cond_kernel, dim3(n), dim3(128), 0, st, M, n_frames, d_feat, feat_stride, feat_stream_stride,
                            d_state, d_fc_base, d_cond, d_lpc);
-    hipLaunchKernelGGL(lpcn::frame_proj_kernel, dim3((unsigned)((items + lpcn::FT - 1) / lpcn::FT)), dim3(128), 0, st, M, items, (const float *)d_cond, d_cond_a, d_cond_b);
+    {
+#define LPCN_PJ(FTV) hipLaunchKernelGGL(lpcn::frame_proj_kernel<FTV>, dim3((unsigned)((items + FTV - 1) / FTV), items <= LPCN_PROJ_SPLIT_MAX ? LPCN_ROWS_A / 128 + 1 : 1), dim3(128), 0, st, M, items, (const float *)d_cond, d_cond_a, d_cond_b)
+        if (items > 4) LPCN_PJ(lpcn::FT); else if (items > 2) LPCN_PJ(4); else if (items == 2) LPCN_PJ(2); else LPCN_PJ(1);
+#undef LPCN_PJ
+    }
     if (M.end2end)
         hipLaunchKernelGGL(lpcn::rc2lpc_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, M, (int)items, (const float *)d_cond, d_lpc);
     else

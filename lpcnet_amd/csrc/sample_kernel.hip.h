@@ -21,12 +21,12 @@
 //     broadcasts folded into the multiplies -- LDS traffic is 1/S of the naive scheme.
 //     int8 blobs: the state is quantised once per sample; v_dot4_i32_i8 per (item, stream).
 //   * GRU-B input weights (<=73.7 KB) + recurrent matrix live in LDS; one wave per stream, one lane per output row, gates
-//     exchanged with wave shuffles (no barrier).  Its state operand -- the same 384 values for every row -- does NOT come
-//     from LDS: the gate stage mirrors the new GRU-A state into an L2-resident buffer and the stream's GRU-B wave pulls it
-//     through the scalar cache into SGPRs (s_load_dwordx16 = 4 blocks), used as SGPR-pair operands of v_pk_mul_f32.  The
-//     whole 96-block loop is one hand-scheduled assembly block (grub_scalar_loop.inc, tools/gen_grub_asm.py): a scalar
-//     load must never be in flight across an inline-asm boundary.  (Float blobs with a dense GRU-B input matrix; int8
-//     blobs and block-sparse matrices keep the state in LDS.)
+//     exchanged with wave shuffles (no barrier).  Float blobs with a dense GRU-B input matrix: its state operand -- the same
+//     384 values for every row -- is a BROADCAST LDS read of the block the gate stage has just written, and the whole 96-block
+//     loop is one hand-scheduled assembly block (grub_lds_loop_s{1,2,4}.inc, tools/gen_grub_asm.py --lds S; round 4).
+//     (LPCN_GRUB_LDS=0 builds keep round 3's form: the gate stage mirrors the new state into an L2-resident buffer and the
+//     GRU-B wave pulls it through the scalar cache into SGPR-pair operands of v_pk_mul_f32, grub_scalar_loop.inc.)  int8 blobs
+//     and block-sparse matrices use the LDS + DPP / dot4 forms below.
 //   * dual-FC tree: all 255 nodes x 2 channels are evaluated in parallel (lane = node,channel;
 //     18 weight VGPRs), a ballot per wave yields the 255 decision bits.  Speculative evaluation
 //     is exact: every node's logit is a pure function of the GRU-B state.
@@ -45,6 +45,15 @@
 //   The mirror stores of P2 are not waited for at B2: every wave bumps an LDS arrival counter once its stores are
 //   acknowledged by L2, and a GRU-B wave starts its scalar loads when all eight have arrived (it forms the recurrent part
 //   meanwhile).
+//
+// Round 5:
+//   * int8 blobs, <= 2 streams per workgroup (two workgroups per CU): GRU-B's chain waves are 2 and 3, not 0 and 1 -- wave 0 also leads the
+//     streams, waves w and w + 4 share a SIMD, and two co-resident workgroups are bound by their busiest SIMD; the six other waves all carry
+//     candidate heads of up to 22 items (lpcnet_engine.h: LPCN_I8_GBWA / _GBWB, LPCN_DEAL_HMASK_I8, LPCN_DEAL_EH_I8).
+//   * float blobs with more than 32 items per lane keep 28 in VGPRs and STREAM the rest from L2 every sample (see NR / fetch_w): no variant
+//     has a scratch access inside the sample loop any more, and 48 items per lane (1.83 x the benchmark model's blocks) load.
+//   * a ring of PRODUCTS for GRU-B's last ten blocks at four streams per workgroup (LPCN_GRUB_RING) was built, is bit-exact and is slower;
+//     it stays as a compile-time switch with its phase tables (profiles/r05_phase_clocks_grub_ring.txt).
 //
 // FAST (lpcnet_batch_set_fast) frees the order of a row's sum, and the kernel then uses the matrix pipe: a GRU-A item is
 // four v_mfma_f32_4x4x1 (4 rows' weights x 4 streams' state values per quad), and -- float blobs, dense GRU-B -- the GRU-B

@@ -12,11 +12,20 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 @pytest.fixture(scope="module")
-def rows(tmp_path_factory):
+def analysed(tmp_path_factory):
+    """every streams-per-workgroup value compiled to assembly ONCE (device code only, the three in parallel: ~2 minutes) and analysed"""
     import kernel_resources as kr
-    path = str(tmp_path_factory.mktemp("asm") / "sample_s4.s")
-    kr.compile_asm(4, path)                                 # ~1 minute: every S = 4 variant, device code only
-    return {(r["NW"], r["int8"], r["fast"]): r for r in kr.analyse(path) if not r["pack2"]}
+    from concurrent.futures import ThreadPoolExecutor
+    d = tmp_path_factory.mktemp("asm")
+    paths = {sv: str(d / f"sample_s{sv}.s") for sv in (1, 2, 4)}
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        list(ex.map(lambda sv: kr.compile_asm(sv, paths[sv]), (1, 2, 4)))
+    return {sv: kr.analyse(paths[sv]) for sv in (1, 2, 4)}
+
+
+@pytest.fixture(scope="module")
+def rows(analysed):
+    return {(r["NW"], r["int8"], r["fast"]): r for r in analysed[4] if not r["pack2"]}
 
 
 def test_no_scratch_access_inside_the_sample_loop(rows):
@@ -34,29 +43,23 @@ def test_no_scratch_access_inside_the_sample_loop(rows):
     assert rows[(30, False, False)]["vgpr_spill"] <= 40
 
 
-def test_two_workgroups_per_cu_variants_stay_out_of_scratch_in_the_loop(tmp_path_factory):
+def test_two_workgroups_per_cu_variants_stay_out_of_scratch_in_the_loop(analysed):
     """the 128-VGPR int8 variants (S <= 2, 32 items per lane): spills allowed outside, none inside the sample loop"""
-    import kernel_resources as kr
-    path = str(tmp_path_factory.mktemp("asm2") / "sample_s2.s")
-    kr.compile_asm(2, path)
-    packed = [r for r in kr.analyse(path) if r["pack2"]]
+    packed = [r for r in analysed[2] if r["pack2"]]
     assert len(packed) == 2                                 # PARITY and FAST
     for r in packed:
         assert r["int8"] and r["NW"] == 32 and r["vgpr"] <= 128 and r["scratch_insts_in_sample_loop"] == 0, r
 
 
-def test_fast_fmac_dpp_hazards(rows, tmp_path_factory):
+def test_fast_fmac_dpp_hazards(rows, analysed):
     """the hand-written v_fmac_f32_dpp of FAST float GRU-B sits inside inline assembly, where LLVM's hazard recogniser does not
     look: VALU-write -> DPP-read (2 slots, register ranges included) and EXEC-write -> DPP (5 slots) are checked on the
     assembly of every streams-per-workgroup value (S = 1 and 2 were unchecked)."""
-    import kernel_resources as kr
     for key, r in rows.items():
         if key[2] and not key[1]:
             assert r["dpp_hazard_violations"] == 0, key     # (S >= 2: GRU-B and GRU-A both run on the matrix pipe, the DPP loop is gone)
     for sv in (1, 2):
-        path = str(tmp_path_factory.mktemp(f"asm_s{sv}") / f"sample_s{sv}.s")
-        kr.compile_asm(sv, path)
-        fast_float = [r for r in kr.analyse(path) if r["fast"] and not r["int8"]]
+        fast_float = [r for r in analysed[sv] if r["fast"] and not r["int8"]]
         assert len(fast_float) == 7
         for r in fast_float:
             assert (r["fmac_dpp"] >= 16 or sv > 1) and r["dpp_hazard_violations"] == 0, (sv, r["NW"], r["dpp_hazard_violations"])

@@ -6,7 +6,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-RND=${1:-r04}
+RND=${1:-r05}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 # kernel stats + HBM traffic first: bench.py quotes `roofline.traffic` from profiles/<round>_hbm_traffic*.json, which must have been
@@ -25,6 +25,18 @@ python tools/profile_summarize.py $RND > /dev/null 2>&1
 timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 timeout 300 python bench.py --int8 > $OUT/bench_i8.json 2> $OUT/bench_i8.err
 timeout 300 python bench.py --streams 1 --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err      # BASELINE config 1
+# the operating point the metric is named after: one frame per step for every stream against the 10-ms deadline, >= 500 steps
+timeout 600 python bench.py --rt --steps 500 --rt-sweep 1024,4096,7168,7424,7680,8192 --no-cpu-baseline > $OUT/bench_rt_f32.json 2> $OUT/bench_rt_f32.err
+timeout 600 python bench.py --rt --steps 500 --rt-sweep 1024,8192,9216,9728,10240,10752 --no-cpu-baseline --int8 > $OUT/bench_rt_int8.json 2> $OUT/bench_rt_int8.err
+# denser GRU-A models: the variants that stream their items past the 28th from L2
+for dn in nw32:0.06,0.06,0.22 nw36:0.07,0.07,0.25 nw40:0.08,0.08,0.3 nw48:0.1,0.1,0.35; do
+  timeout 300 python bench.py --densities ${dn#*:} --no-cpu-baseline > $OUT/bench_denseA_${dn%%:*}.json 2> $OUT/bench_denseA_${dn%%:*}.err
+done
+# throughput at other batch sizes
+for ns in 256 512 2048 4096 8192; do
+  timeout 300 python bench.py --streams $ns --no-cpu-baseline --steps 6 --warmup 2 > $OUT/bench_f32_n$ns.json 2> $OUT/bench_f32_n$ns.err
+  timeout 300 python bench.py --streams $ns --no-cpu-baseline --steps 6 --warmup 2 --int8 > $OUT/bench_i8_n$ns.json 2> $OUT/bench_i8_n$ns.err
+done
 timeout 300 python bench.py --fast --no-cpu-baseline > $OUT/bench_f32_fast.json 2> $OUT/bench_f32_fast.err
 timeout 300 python bench.py --fast --fp16-fc --no-cpu-baseline > $OUT/bench_f32_fast_f16.json 2> $OUT/bench_f32_fast_f16.err
 timeout 300 python bench.py --int8 --fast --spw 2 --no-cpu-baseline > $OUT/bench_i8_fast.json 2> $OUT/bench_i8_fast.err

@@ -74,12 +74,26 @@ for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_
                  ("bench_i8_fast.json", "bench_n1_int8_fast.json"), ("rtf_demo.json", "demo_single_stream_rtf.json"),
                  ("bench_f32_fast_f16.json", "bench_n1_fast_fp16fc.json"), ("bench_i8_fast_f16.json", "bench_n1_int8_fast_fp16fc.json"),
                  ("bench_rehearsal_2ranks.json", "bench_rehearsal_2ranks_one_gpu.json"), ("bench_rehearsal_8ranks.json", "bench_rehearsal_8ranks_one_gpu.json"),
-                 ("bench_rehearsal_8ranks_int8.json", "bench_rehearsal_8ranks_one_gpu_int8.json")):
+                 ("bench_rehearsal_8ranks_int8.json", "bench_rehearsal_8ranks_one_gpu_int8.json"),
+                 ("bench_rt_f32.json", "bench_rt_f32.json"), ("bench_rt_int8.json", "bench_rt_int8.json"),
+                 ("bench_denseA_nw32.json", "bench_n1_denseA_nw32.json"), ("bench_denseA_nw36.json", "bench_n1_denseA_nw36.json"),
+                 ("bench_denseA_nw40.json", "bench_n1_denseA_nw40.json"), ("bench_denseA_nw48.json", "bench_n1_denseA_nw48.json")):
     b = os.path.join(SRC, src)
     if os.path.exists(b) and os.path.getsize(b):
         txt = open(b).read()
         js = [ln for ln in txt.split("\n") if ln.startswith("{") and ln.rstrip().endswith("}")]      # (multi-rank runs: gloo prints its connection chatter to stdout too)
         open(os.path.join(DST, f"{RND}_{dst}"), "w").write(js[-1] + "\n" if js and not txt.lstrip().startswith("{\n") else txt)
+# throughput at other batch sizes: one file, one bench line per (flavour, stream count)
+sweep = []
+for fl in ("f32", "i8"):
+    for ns in (256, 512, 2048, 4096, 8192):
+        b = os.path.join(SRC, f"bench_{fl}_n{ns}.json")
+        if os.path.exists(b) and os.path.getsize(b):
+            js = [ln for ln in open(b).read().split("\n") if ln.startswith("{") and ln.rstrip().endswith("}")]
+            if js:
+                sweep.append(js[-1])
+if sweep:
+    open(os.path.join(DST, f"{RND}_bench_stream_sweep.jsonl"), "w").write("\n".join(sweep) + "\n")
 for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast_f32")):
     b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
     if os.path.exists(b):
@@ -92,7 +106,7 @@ if ph:
                 "# columns: B1wait = wait at the barrier behind GRU-A; P2 = GRU-A gates; P3tail = wait at the barrier behind GRU-B; P4 = tree; P5 = leader /\n"
                 "# thresholds; gather, close = GRU-A begin / end work; fcpre = dual-FC prefetch (+ mirror arrival); gruB = GRU-B mat-vec (incl. recurrent part,\n"
                 "# arrival wait, scalar-cache warm-up); items = GRU-A item chain; start = wait for the indices + gather + start values; P5a = GRU-B gates\n"
-                "# (waves 0..3) / early candidate heads (waves 4..7)\n")
+                "# (waves 0..3; int8 at two streams per workgroup: waves 2, 3) / early candidate heads (the other waves)\n")
         for f in ph:
             o.write("## " + os.path.basename(f) + "\n")
             o.write(open(f).read())
