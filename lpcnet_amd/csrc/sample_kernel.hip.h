@@ -973,14 +973,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // The gather-independent half of a start value (bias + diag*h and the frame condition) is read and formed
             // for all three slots before the wave waits for the indices / the gathered rows.
             float pre_b[3][S] = {}, pre_c[3][S] = {};
-#ifndef LPCN_SKIP_EMPTY_SLOTS
-#define LPCN_SKIP_EMPTY_SLOTS 0
-#endif
-            // (1: int8 kernels, 2: all) a wave skips the start values of slots 1 / 2 it owns no rows in -- since round 5's dealing of int8 blobs six of
-            // the 24 wave-slots are empty, and the kernel is bound by its instruction count
-            constexpr bool SKIP_EMPTY = LPCN_SKIP_EMPTY_SLOTS == 2 || (LPCN_SKIP_EMPTY_SLOTS == 1 && I8);
             auto row_pre = [&](const int k, const int slot) {
-                if (SKIP_EMPTY && k > 0 && !((has_slot >> k) & 1)) return;
                 int r = LPCN_ROW(k);
                 LPCN_REMAT_V(r);
                 r = r < 0 ? 0 : r;
@@ -994,7 +987,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
             };
             auto row_init = [&](const int k, const int set, const bool to_acc, const bool park = true) {
-                if (SKIP_EMPTY && k > 0 && !to_acc && !((has_slot >> k) & 1)) return;
                 const int slot = k;
                 int r = LPCN_ROW(k);
                 LPCN_REMAT_V(r);
@@ -1212,15 +1204,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // S = 2: 768 items on 512 lanes -- the second round is empty for waves 4..7; S = 1: 384 items -- waves 6, 7 have none.  A wave
             // runs only the rounds in which it has items (wave-uniform count, one scalar branch): the instructions of an empty round
             // are issue slots taken from the waves that share the SIMD (two workgroups per CU for the int8 kernels).
-            auto gate_stage = [&](auto nqc, const int q0 = 0) __attribute__((always_inline)) {
+            auto gate_stage = [&](auto nqc) __attribute__((always_inline)) {
                 constexpr int NI = NA * S;                                     // items
-                constexpr int NQ = decltype(nqc)::value;                       // rounds of this wave (q0: the first one)
+                constexpr int NQ = decltype(nqc)::value;                       // rounds of this wave
                 constexpr bool FULL = NI % LPCN_WG_THREADS == 0;               // (S = 4: every lane has an item in every round -- no range tests, no selects)
                 if constexpr (NQ > 0) {
                 float z[NQ], rg[NQ], a[NQ], hold[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int i = tid + (q + q0) * LPCN_WG_THREADS;
+                    const int i = tid + q * LPCN_WG_THREADS;
                     const int ic = (FULL || i < NI) ? i : 0;
                     z[q] = sm_pre[ic];
                     rg[q] = sm_pre[NI + ic];
@@ -1231,14 +1223,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 for (int q = 0; q < NQ; ++q) { z[q] = act_sigmoid<FAST>(z[q], sm_tansig); rg[q] = act_sigmoid<FAST>(rg[q], sm_tansig); }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int i = tid + (q + q0) * LPCN_WG_THREADS;
+                    const int i = tid + q * LPCN_WG_THREADS;
                     a[q] = a[q] * rg[q] + sm_inh[(FULL || i < NI) ? i : 0];
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) a[q] = act_tanh<FAST>(a[q], sm_tansig);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int i = tid + (q + q0) * LPCN_WG_THREADS;
+                    const int i = tid + q * LPCN_WG_THREADS;
                     const int n = i / S, s = i % S;
                     const float hnew = z[q] * hold[q] + (1.f - z[q]) * a[q];      // src/nnet.c:447
                     const float hv = ((live_mask >> s) & 1) ? hnew : hold[q];
@@ -1266,13 +1258,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                                 // The empty round's instructions are not what the phase waits for, and the wave-divergent paths cost more at the barrier than they save.
 #endif
                 if constexpr (NI % LPCN_WG_THREADS == 0 || !LPCN_GATE_ROUNDS) gate_stage(std::integral_constant<int, NQ_MAX>{});
-                else if constexpr (LPCN_GATE_ROUNDS == 2) {
-                    // one round at a time, as many as this wave has items in (wave-uniform trip count, ONE copy of the code)
-                    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-                    const int nq = ((NQ_MAX - 1) * LPCN_WG_THREADS + wv * 64 < NI) ? NQ_MAX : NQ_MAX - 1;
-#pragma unroll 1
-                    for (int q0 = 0; q0 < nq; ++q0) gate_stage(std::integral_constant<int, 1>{}, q0);
-                } else {
+                else {
                     // this wave's lanes are tid0 = 64 w .. 64 w + 63: round q holds items for it iff q * 512 + 64 w < NI
                     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
                     if ((NQ_MAX - 1) * LPCN_WG_THREADS + wv * 64 < NI) gate_stage(std::integral_constant<int, NQ_MAX>{});
