@@ -112,6 +112,30 @@ def test_sample_loop_seam(blob_f32, batch4):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 9])
+def test_one_frame_steps_for_small_batches_match_oracle(n, blob_f32, hip_lib):
+    """round 5: the frame kernels' tile size is a template parameter (1 / 2 / 4 / 8 streams of one frame each, 1 / 2 / 4 / 8 (stream, frame)
+    items in the projection, whose row blocks are separate workgroups for small batches): every instantiation, frame by frame and in
+    chunks of 2 / 3 frames, PCM and frame products against the oracle"""
+    T = 7
+    feats = feats_for(range(7300, 7300 + n), T)
+    want, ca, cb, lp, _ = oracle_run(blob_f32, feats, with_products=True)
+    b = api.LPCNetBatch(n, blob_f32)
+    got = np.concatenate([b.synthesize(np.ascontiguousarray(feats[:, t:t + 1])) for t in range(T)], axis=1)
+    assert np.array_equal(got, want), n
+    b.reset()
+    got = np.concatenate([b.synthesize(np.ascontiguousarray(feats[:, a:z])) for a, z in ((0, 2), (2, 5), (5, 7))], axis=1)
+    assert np.array_equal(got, want), n
+    b.reset()
+    a_, b_, l_ = b.run_frames(feats)
+    assert np.array_equal(a_, ca) and np.array_equal(b_, cb) and np.array_equal(l_, lp)
+    b.reset()
+    for t in range(T):                                         # ... and the frame network alone, one frame per call
+        a_, b_, l_ = b.run_frames(np.ascontiguousarray(feats[:, t:t + 1]))
+        assert np.array_equal(a_[:, 0], ca[:, t]) and np.array_equal(b_[:, 0], cb[:, t]) and np.array_equal(l_[:, 0], lp[:, t]), (n, t)
+    b.close()
+
+
 def test_streaming_calls_equal_one_call_and_chunking(blob_f32, hip_lib):
     """state carried across calls; n_frames above the internal 100-frame chunk; single-frame calls."""
     n, T = 2, 104
