@@ -96,7 +96,9 @@ def build(force=False, verbose=True, prof=False):
     objs += [j[-1] for j in jobs]
     for c in ("api.c", "model_pack.c"):
         o = os.path.join(objdir, c[:-2] + ".o")
-        run(["gcc"] + C_FLAGS + [f'-DLPCN_SOURCE_HASH="{h_src}"', f'-DLPCN_DEVICE_SOURCE_HASH="{h_dev}"', "-c", os.path.join(CSRC, c), "-o", o])
+        # (the -D switches of an experiment reach the host C files too: lpcnet_engine.h's dealing defaults -- e.g. which waves of an int8 blob may
+        # carry candidate heads -- are derived from the same macros the kernels are compiled with)
+        run(["gcc"] + C_FLAGS + [x for x in extra if x.startswith("-D")] + [f'-DLPCN_SOURCE_HASH="{h_src}"', f'-DLPCN_DEVICE_SOURCE_HASH="{h_dev}"', "-c", os.path.join(CSRC, c), "-o", o])
         objs.append(o)
     run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread", "-lm"])
     return lib
