@@ -342,29 +342,6 @@ template <bool FAST> __device__ __forceinline__ float act_sigmoid(const float x,
     else return lpcn_sigmoid(x, tab);
 }
 
-// The table activations over a PAIR of values held in a register pair: the same operations in the same order per element (lpcnet_math.h),
-// written on 2-vectors so that the multiplies and adds become v_pk_mul_f32 / v_pk_add_f32 -- each half is rounded on its own
-// (lpcnet_hip_arith_identities_device pins that), so the results are bit for bit the scalar ones
-typedef float lpcn_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ lpcn_f2 lpcn_tanh2(const lpcn_f2 x, const float *tab)
-{
-    const lpcn_f2 ax = {fabsf(x[0]), fabsf(x[1])};
-    const lpcn_f2 t = .5f + 25.f * ax;
-    int i0 = (int)t[0], i1 = (int)t[1];
-    i0 = i0 > 200 ? 200 : i0;
-    i1 = i1 > 200 ? 200 : i1;
-    const lpcn_f2 fi = {(float)i0, (float)i1};
-    const lpcn_f2 dx = ax - .04f * fi;
-    const lpcn_f2 y = {tab[i0], tab[i1]};
-    const lpcn_f2 dy = 1.f - y * y;
-    const lpcn_f2 r = y + dx * dy * (1.f - y * dx);
-    return (lpcn_f2){x[0] < 0 ? -r[0] : r[0], x[1] < 0 ? -r[1] : r[1]};
-}
-__device__ __forceinline__ lpcn_f2 lpcn_sigmoid2(const lpcn_f2 x, const float *tab)
-{
-    return .5f + .5f * lpcn_tanh2(.5f * x, tab);
-}
-
 // FAST = the arithmetic of the reference's SIMD builds instead of its generic-C order: fused multiply-add for float
 // blobs (src/vec_avx.h:790-858 _mm256_fmadd_ps), int32 block accumulation for int8 blobs (see acc_start).  Results are
 // no longer bit-identical to the generic-C build; tests/test_gpu_fast.py bounds the deviation teacher-forced.
@@ -1242,29 +1219,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     a[q] = sm_pre[2 * NI + ic];
                     hold[q] = sm_hT[ic];
                 }
-#ifndef LPCN_PK_ACT
-#define LPCN_PK_ACT 0           // 1: the gate stage's activations over item pairs (rounds 0 and 1 of a lane) as packed math; 2: the tree's too
-#endif
-                constexpr int QP = (LPCN_PK_ACT && !FAST && NQ >= 2) ? 2 : 0;     // rounds handled as a pair
-                if constexpr (QP == 2) {
-                    lpcn_f2 z2 = {z[0], z[1]}, r2 = {rg[0], rg[1]}, a2 = {a[0], a[1]};
-                    z2 = lpcn_sigmoid2(z2, sm_tansig);
-                    r2 = lpcn_sigmoid2(r2, sm_tansig);
-                    const int i1 = tid + LPCN_WG_THREADS;
-                    const lpcn_f2 in2 = {sm_inh[tid], sm_inh[(FULL || i1 < NI) ? i1 : 0]};
-                    a2 = a2 * r2 + in2;
-                    a2 = lpcn_tanh2(a2, sm_tansig);
-                    z[0] = z2[0]; z[1] = z2[1]; a[0] = a2[0]; a[1] = a2[1];
-                }
 #pragma unroll
-                for (int q = QP; q < NQ; ++q) { z[q] = act_sigmoid<FAST>(z[q], sm_tansig); rg[q] = act_sigmoid<FAST>(rg[q], sm_tansig); }
+                for (int q = 0; q < NQ; ++q) { z[q] = act_sigmoid<FAST>(z[q], sm_tansig); rg[q] = act_sigmoid<FAST>(rg[q], sm_tansig); }
 #pragma unroll
-                for (int q = QP; q < NQ; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int i = tid + q * LPCN_WG_THREADS;
                     a[q] = a[q] * rg[q] + sm_inh[(FULL || i < NI) ? i : 0];
                 }
 #pragma unroll
-                for (int q = QP; q < NQ; ++q) a[q] = act_tanh<FAST>(a[q], sm_tansig);
+                for (int q = 0; q < NQ; ++q) a[q] = act_tanh<FAST>(a[q], sm_tansig);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int i = tid + q * LPCN_WG_THREADS;
@@ -1905,23 +1868,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     if (lane == 0) {
 #pragma unroll
                         for (int s = 0; s < S; ++s) sm_mask[s * 8 + wave] = mk[s];
-                    }
-                } else if constexpr (LPCN_PK_ACT == 2 && !FAST && S >= 2) {
-                    // stream PAIRS: two sums (each its own chain, j = 0..15 in order), then the table tanh of both as packed math
-#pragma unroll
-                    for (int s = 0; s < S; s += 2) {
-                        float sum0 = fcb, sum1 = fcb;
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) { sum0 = sum0 + fcw[j] * sm_hB[s * NB + j]; sum1 = sum1 + fcw[j] * sm_hB[(s + 1) * NB + j]; }
-                        const lpcn_f2 v2 = fcf * lpcn_tanh2((lpcn_f2){sum0, sum1}, sm_tansig);
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const float v = v2[k];
-                            const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-                            const float lg = v + vo;
-                            const unsigned long long m = __ballot(sm_thr[(s + k) * 8 + node_level] < lg) & (wave == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
-                            if (lane == 0) sm_mask[(s + k) * 8 + wave] = m;
-                        }
                     }
                 } else {
 #pragma unroll
