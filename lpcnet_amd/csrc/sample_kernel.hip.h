@@ -143,9 +143,6 @@ template <typename T> __device__ __forceinline__ LPCN_GLOBAL T *as_global_rw(T *
 #ifndef LPCN_PROD_BLOCKS
 #define LPCN_PROD_BLOCKS 48
 #endif
-#ifndef LPCN_I8_TREE2L
-#define LPCN_I8_TREE2L 0        // 1: int8 blobs at two streams per workgroup -- tree levels 0..6 speculatively with one stream per lane, level 7 on the leader (see Lds<S>::TREE2L)
-#endif
 #ifndef LPCN_GRUB_RING
 #define LPCN_GRUB_RING 0        // 1 / 2: four float streams per workgroup -- waves 4..7 form the products of GRU-B's last 10 blocks of their partner stream before / after their
                                 // candidate heads (see Lds<S>::RING_BLOCKS).  MEASURED AND NOT KEPT (round 5): bit-exact, 125.6 (before) / 121.5 (after) vs 126.8 M
@@ -193,19 +190,7 @@ template <int S> struct Lds {
     static constexpr int RING_BLOCKS = 10, RING_FIRST = 96 - RING_BLOCKS, RING_SEG0 = 4, RING_SEG1 = 2, RING_SEG2 = 4;
     static constexpr int prod_sz = S == 1 ? (PROD_BLOCKS + 7) * RB * 16 : (S == 4 && LPCN_GRUB_RING ? S * RING_SEG2 * RB * 16 : 0);      // (S = 1, + 7 blocks: the chain wave's ring of eight reads ahead past the last block on its last trip)
     static constexpr int prod(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }
-    // int8 blobs, two streams per workgroup (LPCN_I8_TREE2L): the dual-FC rows of the tree's LAST level (nodes 128..255: 128 x 2 channels x 16
-    // floats + bias + factor = 18 432 B) live in LDS, so that only levels 0..6 are evaluated speculatively -- 127 nodes x 2 channels = 254 lanes
-    // per stream, ONE stream per lane instead of two -- and the leader evaluates the one node of level 7 its walk arrives at.  Two workgroups
-    // share a CU (81 920 B each): the biases and factors and the first 8 rows sit in bytes the int8 layout does not use (the float-sized
-    // recurrent matrix of GRU-B: 2 304 B; the float-sized block-ordered state: 1 888 B at S = 2), the other 120 rows behind everything else.
-    static constexpr bool TREE2L = LPCN_I8_TREE2L && S == 2;
-    static constexpr int t7_bias = brec + RB * 16;                 // [2][128] f32 (int8 blobs use RB x 16 B of brec)
-    static constexpr int t7_rows_lo = t7_bias + 1024;               // rows of nodes 128..135
-    static constexpr int t7_fac = hA + 768 * S + 16 * S;            // [2][128] f32 behind xq / xqT / hBq
-    static constexpr int T7_LO = 8, t7_tail_sz = TREE2L ? (128 - T7_LO) * 128 : 0;
-    static_assert(!TREE2L || (t7_rows_lo + T7_LO * 128 <= bbias && t7_fac + 1024 <= hA + hA_sz), "the int8 layout's holes hold the last tree level's biases, factors and first rows");
-    static constexpr int t7_rows_hi(int nb_b) { return hBh(nb_b, true) + S * 32; }      // rows of nodes 136..255
-    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? t7_tail_sz : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
+    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? 0 : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
     static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
     static constexpr int xqT    = hA + 384 * S;                     // [S][96] dwords: the same, stream-major (GRU-B input)
@@ -305,13 +290,6 @@ template <int J> __device__ __forceinline__ float row_bcast(float v)
 template <int J> __device__ __forceinline__ float lpc_chain(float r, float prod)
 {
     if constexpr (J < LPCN_LPC_ORDER) return lpc_chain<J + 1>(r - row_bcast<J>(prod), prod);
-    else return r;
-}
-
-// r + p(lane 0) + p(lane 1) + ... + p(lane 15) of the caller's 16-lane row, added in that order (the dual FC's sum over its 16 inputs, src/nnet.c:194-199)
-template <int J> __device__ __forceinline__ float row_sum_chain(float r, float prod)
-{
-    if constexpr (J < LPCN_N_B) return row_sum_chain<J + 1>(r + row_bcast<J>(prod), prod);
     else return r;
 }
 
@@ -603,19 +581,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             sm_hB[i] = hv0;
             if constexpr (I8) smem[L::hBq + i] = (unsigned char)quant_s8(hv0);
             if constexpr (FAST) ((_Float16 *)(smem + L::hBh(Ap->nb_b, I8)))[i] = (_Float16)hv0;
-        }
-        if constexpr (I8 && !FAST && L::TREE2L) {
-            // the last tree level's rows (fc_w is [node][channel][16]: nodes 128..255 are one contiguous 16 KB), biases and factors
-            const auto *fw = as_global(Ap->fc_w), *fb = as_global(Ap->fc_b), *ff = as_global(Ap->fc_f);
-            for (int i = tid; i < 128 * 32; i += LPCN_WG_THREADS) {
-                const int nd = i >> 5, k = i & 31;
-                float *dst = nd < L::T7_LO ? (float *)(smem + L::t7_rows_lo) + nd * 32 + k : (float *)(smem + L::t7_rows_hi(Ap->nb_b)) + (nd - L::T7_LO) * 32 + k;
-                *dst = fw[(128 + nd) * 32 + k];
-            }
-            for (int i = tid; i < 256; i += LPCN_WG_THREADS) {
-                ((float *)(smem + L::t7_bias))[i] = fb[(i >> 7) * 256 + 128 + (i & 127)];
-                ((float *)(smem + L::t7_fac))[i] = ff[(i >> 7) * 256 + 128 + (i & 127)];
-            }
         }
         // leader-lane state (lane s of wave 0 leads stream s); kept in LDS between samples
         if (tid < S) {
@@ -1310,8 +1275,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // runs.  Re-fetched every sample: 18 VGPRs that must not stay live across the GRU-A loop.
             // (tried: the GRU-B waves issue these loads only after their mat-vec -- the ~0.1 k clk saved in front of GRU-B
             // come back as a later tree phase: 102.3 vs 102.2 M samples/s, not kept)
-            constexpr bool T2L = I8 && !FAST && L::TREE2L;     // (two streams: waves 0..3 evaluate stream 0's nodes 0..127, waves 4..7 stream 1's)
-            const int node = T2L ? (tid & 255) >> 1 : tid >> 1, chan = tid & 1;
+            const int node = tid >> 1, chan = tid & 1;
             const auto *fcw_ptr = fc_w_g + node * 2 * NB + chan * NB;
             float fcw[NB], fcb = 0.f, fcf = 0.f;
             bool fc_f16 = false;
@@ -1905,17 +1869,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
                         for (int s = 0; s < S; ++s) sm_mask[s * 8 + wave] = mk[s];
                     }
-                } else if constexpr (T2L) {
-                    // levels 0..6 only, this lane's node for ONE stream (the wave's half of the workgroup)
-                    const int ts = wave >> 2;
-                    float sum = fcb;
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) sum = sum + fcw[j] * sm_hB[ts * NB + j];                          // src/nnet.c:194-199
-                    const float v = fcf * act_tanh<FAST>(sum, sm_tansig);
-                    const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-                    const float lg = v + vo;                                        // sum1 += sum2
-                    const unsigned long long m = __ballot(sm_thr[ts * 8 + node_level] < lg) & ((wave & 3) == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
-                    if (lane == 0) sm_mask[ts * 8 + (wave & 3)] = m;               // (qwords 0..3 of the stream's mask row: nodes 0..127, as before)
                 } else {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
@@ -1985,19 +1938,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         const unsigned lo = (k & 1) ? qb[1] : qb[0], hi = (k & 1) ? qb[3] : qb[2];
                         val = (val << 1) | bit_of((k & 2) ? hi : lo, val & 15);
                     }
-                    if constexpr (T2L) {
-                        // the walk has arrived at node 128 + val of the last level, which nobody has evaluated: the 16 lanes of the stream's row
-                        // do it now -- lane j forms the products of input j for both channels, every lane adds them up in input order
-                        // (DPP row broadcasts; the row's lanes are all active here), table tanh, factor, the two channels, the threshold
-                        (void)qc; (void)qd;
-                        const int tp = (int)(threadIdx.x & 15u);
-                        const float *row = val < L::T7_LO ? (const float *)(smem + L::t7_rows_lo) + val * 32 : (const float *)(smem + L::t7_rows_hi(Ap->nb_b)) + (val - L::T7_LO) * 32;
-                        const float hj = sm_hB[lrow * NB + tp];
-                        const float s0 = row_sum_chain<0>(((const float *)(smem + L::t7_bias))[val], row[tp] * hj);
-                        const float s1 = row_sum_chain<0>(((const float *)(smem + L::t7_bias))[128 + val], row[NB + tp] * hj);
-                        const float lg = ((const float *)(smem + L::t7_fac))[val] * lpcn_tanh(s0, sm_tansig) + ((const float *)(smem + L::t7_fac))[128 + val] * lpcn_tanh(s1, sm_tansig);
-                        val = (val << 1) | (sm_thr[lrow * 8 + 7] < lg ? 1 : 0);
-                    } else {
+                    {
                         const int k = val >> 4;                                                          // nodes 128..255: dwords 8..15
                         const unsigned a0 = (k & 1) ? qc[1] : qc[0], a1 = (k & 1) ? qc[3] : qc[2];
                         const unsigned a2 = (k & 1) ? qd[1] : qd[0], a3 = (k & 1) ? qd[3] : qd[2];
@@ -2008,13 +1949,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 };
                 float pcm = 0.f, deemph = 0.f;
                 int exc = 0;                   // (tree_val: the tree's own decision -- teacher forcing overrides exc)
-                int tree_val_t2l = 0;          // (T2L: the walk needs the whole row of lanes, it cannot be repeated in the one-lane trace branch)
                 if (live) {                                  // (all 16 lanes of a stream's row do the same walk)
                     const float pred = sm_lead[lrow * 8 + 0];           // (issued together with the mask reads)
                     deemph = sm_lead[lrow * 8 + 1];
                     const int val = walk_tree(lrow);
                     exc = val;
-                    if constexpr (T2L) tree_val_t2l = val;
                     if (smp < preload) {                                        // src/lpcnet.c:256-258
                         const float x = (float)sm_pcm[lrow * LPCN_FRAME_SIZE + smp];
                         exc = lpcn_lin2ulaw(x - 0.85f * deemph - pred);
@@ -2046,7 +1985,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                             // any use of the leader's value this far down (a register, an extra LDS store) cost 17 spilled
                             // SGPRs in the sample loop and 2.3 % of the float kernel
                             asm volatile("" ::: "memory");
-                            if constexpr (T2L) d[6] = (float)tree_val_t2l; else d[6] = (float)walk_tree(lrow);
+                            d[6] = (float)walk_tree(lrow);
                         }
                         pcm = pcm + 0.85f * deemph;
                         sm_lead[lrow * 8 + 1] = pcm;                            // de-emphasis memory
