@@ -1947,42 +1947,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                     return val;
                 };
-#ifndef LPCN_TREE_WALK_PAR
-#define LPCN_TREE_WALK_PAR 0
-#endif
-                // The same 8 decisions found by the row's 16 lanes in TWO dependent steps instead of eight: a 4-level subtree has 16 root-to-leaf
-                // paths and exactly one of them agrees with the decisions of the nodes it passes -- lane c tests path c (four independent bit tests),
-                // a ballot names the lane that matched.  First the top four levels (nodes 1..15: one dword), then the four levels under the node the
-                // first step arrived at.  Must be called by all 16 lanes of the row.
-                auto walk_tree_par = [&](const int lrow, const int tp) {
-                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                    const u4 *mk = (const u4 *)(sm_mask + lrow * 8);
-                    const u4 qa = mk[0], qb = mk[1], qc = mk[2], qd = mk[3];
-                    const unsigned c = (unsigned)tp, c3 = c >> 3, c2 = (c >> 2) & 1u, c1 = (c >> 1) & 1u, c0 = c & 1u;
-                    auto bit_at = [](unsigned word, unsigned node) { return (word >> (2u * (node & 15u))) & 1u; };
-                    // step 1: nodes 1, 2 + c3, 4 + (c >> 2), 8 + (c >> 1) -- all in dword 0
-                    const unsigned w0 = qa[0];
-                    const bool m1 = bit_at(w0, 1u) == c3 && bit_at(w0, 2u + c3) == c2 && bit_at(w0, 4u + (c >> 2)) == c1 && bit_at(w0, 8u + (c >> 1)) == c0;
-                    const unsigned long long b1 = __ballot(m1);
-                    const unsigned v4 = (unsigned)__builtin_ctz(((unsigned)(b1 >> (16 * lrow)) & 0xFFFFu) | 0x10000u);
-                    // step 2: nodes 16 + v4 (dword 1), 32 + 2 v4 + c3 (dwords 2..3), 64 + 4 v4 + (c >> 2) (dwords 4..7), 128 + 8 v4 + (c >> 1) (dwords 8..15)
-                    const unsigned d5 = (v4 & 8u) ? qa[3] : qa[2];
-                    const unsigned e0 = (v4 & 4u) ? qb[1] : qb[0], e1 = (v4 & 4u) ? qb[3] : qb[2];
-                    const unsigned d6 = (v4 & 8u) ? e1 : e0;
-                    const unsigned f0 = (v4 & 2u) ? qc[1] : qc[0], f1 = (v4 & 2u) ? qc[3] : qc[2], f2 = (v4 & 2u) ? qd[1] : qd[0], f3 = (v4 & 2u) ? qd[3] : qd[2];
-                    const unsigned g0 = (v4 & 4u) ? f1 : f0, g1 = (v4 & 4u) ? f3 : f2;
-                    const unsigned d7 = (v4 & 8u) ? g1 : g0;
-                    const bool m2 = bit_at(qa[1], v4) == c3 && bit_at(d5, 2u * v4 + c3) == c2 && bit_at(d6, 4u * v4 + (c >> 2)) == c1 && bit_at(d7, 8u * v4 + (c >> 1)) == c0;
-                    const unsigned long long b2 = __ballot(m2);
-                    const unsigned v8 = (unsigned)__builtin_ctz(((unsigned)(b2 >> (16 * lrow)) & 0xFFFFu) | 0x10000u);
-                    return (int)((v4 << 4) | v8);
-                };
                 float pcm = 0.f, deemph = 0.f;
                 int exc = 0;                   // (tree_val: the tree's own decision -- teacher forcing overrides exc)
                 if (live) {                                  // (all 16 lanes of a stream's row do the same walk)
                     const float pred = sm_lead[lrow * 8 + 0];           // (issued together with the mask reads)
                     deemph = sm_lead[lrow * 8 + 1];
-                    const int val = LPCN_TREE_WALK_PAR ? walk_tree_par(lrow, tap) : walk_tree(lrow);
+                    const int val = walk_tree(lrow);
                     exc = val;
                     if (smp < preload) {                                        // src/lpcnet.c:256-258
                         const float x = (float)sm_pcm[lrow * LPCN_FRAME_SIZE + smp];
