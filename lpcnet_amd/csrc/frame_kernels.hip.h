@@ -188,11 +188,11 @@ __global__ __launch_bounds__(128) void frame_cond_kernel(LpcnFrameModel M, int n
 // throws 7 of its 8 accumulators away: 0.81 ms for 8 192 streams (8 % of the 10-ms step), L2-bandwidth bound.  Same arithmetic per
 // output (inputs in ascending order, multiply and add rounded separately): bit-identical to F1.
 // ---------------------------------------------------------------------------------------------
-constexpr int ST_MAX = 8;        // streams per tile of a full batch
-// (round 5: ST is a template parameter -- a batch of one to four streams, i.e. every call of the reference's per-frame API that finds no
-// company in the combining dispatcher, ran eight accumulators for one stream: 58 us per frame for a single stream, instruction-bound on
-// two waves; and the weight loops carry an unroll hint so that a lane has LPCN_FRAME_UNROLL L2 loads in flight instead of one per
-// trip -- rocprofv3 on the reference's demo: frame_cond 57.7 -> see EXPERIMENTS.md us, frame_proj 75.6 -> us per frame)
+// (round 5: ST -- streams per tile, 8 for a full batch -- is a template parameter: a batch of one to four streams, i.e. every call of the
+// reference's per-frame API that finds no company in the combining dispatcher, ran eight accumulators for one stream, instruction-bound on
+// two waves; and the weight loops carry an unroll hint so that a lane has LPCN_FRAME_UNROLL L2 loads in flight instead of one per trip.
+// rocprofv3 on the reference's demo, one stream, per frame: this kernel 57.7 us and frame_proj 75.6 us before, ~40 us for all frame
+// kernels together after)
 template <int ST>
 __global__ __launch_bounds__(128) void frame_cond_t1_kernel(LpcnFrameModel M, int n_streams, const float *feat, size_t feat_stream_stride,
                                                             lpcn_stream_state *states, int *fc_base, float *cond_out /*[stream][128]*/,

@@ -1204,6 +1204,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // S = 2: 768 items on 512 lanes -- the second round is empty for waves 4..7; S = 1: 384 items -- waves 6, 7 have none.  A wave
             // runs only the rounds in which it has items (wave-uniform count, one scalar branch): the instructions of an empty round
             // are issue slots taken from the waves that share the SIMD (two workgroups per CU for the int8 kernels).
+            // (tried in round 5: the activations of a lane's first two items as packed math on 2-vectors -- same operations, same order, 35-68 fewer
+            // instructions in the loop, bit-exact, and 2-5 % slower: a packed fp32 instruction costs more here than the two scalar ones it replaces)
             auto gate_stage = [&](auto nqc) __attribute__((always_inline)) {
                 constexpr int NI = NA * S;                                     // items
                 constexpr int NQ = decltype(nqc)::value;                       // rounds of this wave
@@ -1525,7 +1527,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                             // 128-VGPR variants (two workgroups per CU): the other workgroup hides the LDS latency, a
                             // two-quad pipeline is enough and keeps the kernel out of scratch memory
 #ifndef LPCN_I8_GB_DEPTH
-#define LPCN_I8_GB_DEPTH 3      // quads of GRU-B's ring on the 128-VGPR kernels: 2 / 3 / 4 -> 169.2 / 172.0 / see EXPERIMENTS.md M samples/s (round 5, chain waves 2, 3; round 4, chain waves 0, 1: 2 and 3 equal)
+#define LPCN_I8_GB_DEPTH 3      // quads of GRU-B's ring on the 128-VGPR kernels: 2 / 3 / 4 -> 169.2 / 172.0 / 172.1 M samples/s (round 5, chain waves 2, 3; round 4, chain waves 0, 1: 2 and 3 equal)
 #endif
 #ifndef LPCN_I8_GB_ASM
 #define LPCN_I8_GB_ASM 0
@@ -1923,6 +1925,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (tid < 64 && LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(LPCN_LEADER_PRIO);
             if (tid < 16 * S) {
                 const int lrow = (tid & 63) >> 4, tap = tid & 15;
+                // (tried in round 5: the walk by the row's 16 lanes in two dependent steps -- lane c tests the c-th root-to-leaf path of a 4-level
+                // subtree, a ballot names the lane that matched -- a third of the dependent depth, bit-exact, and slower: fp32 123.1 vs 126.3 M,
+                // int8 164.1 vs 170.4 M.  And for int8 blobs at two streams per workgroup: levels 0..6 only with one stream per lane, the last level
+                // evaluated here from an LDS table -- +4.5 % with the tree phase halved, -0.4 % once this wave pays for the extra level)
                 auto walk_tree = [&](int lrow) {             // the sampler's 8 decisions from the 255 ballot bits of stream row lrow
                     typedef unsigned u4 __attribute__((ext_vector_type(4)));
                     const u4 *mk = (const u4 *)(sm_mask + lrow * 8);
