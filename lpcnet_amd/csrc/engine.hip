@@ -73,6 +73,10 @@ struct lpcn_batch_dev {
     short *d_pcm = nullptr;
     size_t feat_cap = 0, pcm_cap = 0;
     LpcnSampleArgs *d_args = nullptr;
+    // HIP-graph capture: a captured launch's argument block must outlive the call (the copy node reads its host source at every replay), so it
+    // is taken from a small pinned pool that lives as long as the batch instead of from the caller's stack
+    LpcnSampleArgs *h_cap_args = nullptr;
+    int cap_used = 0;
     float *d_dbg = nullptr;
     unsigned long long *d_prof = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -87,13 +91,23 @@ struct lpcn_batch_dev {
     float ms_sample = 0.f, ms_frame = 0.f;
 };
 
+#define LPCN_CAPTURE_SLOTS 32
+static bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+}
+// (while the caller's stream is being captured into a HIP graph nothing is executed: the batch's event chain is left alone -- an event
+// recorded inside a capture cannot be waited for from the host -- and ordering replays against other work on the batch is the caller's job)
 static int order_begin(lpcn_batch_dev *b, hipStream_t st)
 {
+    if (stream_is_capturing(st)) return 0;
     if (b->pending && st != b->last_stream) HIP_TRY(hipStreamWaitEvent(st, b->ev_last, 0));
     return 0;
 }
 static int order_end(lpcn_batch_dev *b, hipStream_t st)
 {
+    if (stream_is_capturing(st)) return 0;
     HIP_TRY(hipEventRecord(b->ev_last, st));
     b->last_stream = st;
     b->pending = true;
@@ -388,6 +402,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
     AL(b->d_lpc, sizeof(float) * (size_t)n * max_chunk * LPCN_LPC_ORDER);
     AL(b->d_cond, sizeof(float) * (size_t)n * (max_chunk + 4) * LPCN_COND * 2);
     AL(b->d_args, sizeof(LpcnSampleArgs));
+    if (hipHostMalloc((void **)&b->h_cap_args, sizeof(LpcnSampleArgs) * LPCN_CAPTURE_SLOTS, hipHostMallocDefault) != hipSuccess) b->h_cap_args = nullptr;      // (only capture needs it)
     AL(b->d_vq_mem, sizeof(float) * (size_t)n * LPCN_NB_BANDS);
     AL(b->d_hmir, sizeof(float) * ((size_t)n + 4) * LPCN_N_A);       // workgroups x S slots: the last workgroup may be partly filled
 #undef AL
@@ -405,6 +420,7 @@ extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
     DeviceGuard guard(b->e->device);
     (void)wait_all(b);
     if (b->h_pin) (void)hipHostFree(b->h_pin);
+    if (b->h_cap_args) (void)hipHostFree(b->h_cap_args);
     if (b->ev_last) (void)hipEventDestroy(b->ev_last);
     void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof,
                     b->d_vq_mem, b->d_packets, b->d_hmir, b->d_state_tmp, b->d_map, b->d_keep_a, b->d_keep_b, b->d_keep_lpc};
@@ -516,7 +532,15 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
     a.fc_f16 = (b->e->fast && b->e->fc_f16) ? 1 : 0;
     a.hmir = getenv("LPCNET_HIP_NO_SCALAR_GRUB") ? nullptr : b->d_hmir;      // (tools: the LDS + DPP form of GRU-B for comparison)
-    HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
+    const LpcnSampleArgs *src = &a;
+    if (stream_is_capturing(st)) {
+        if (!b->h_cap_args || b->cap_used >= LPCN_CAPTURE_SLOTS) {
+            snprintf(g_err, sizeof(g_err), "more than %d launches of one batch captured into HIP graphs", LPCN_CAPTURE_SLOTS); return LPCN_E_ARG;
+        }
+        b->h_cap_args[b->cap_used] = a;
+        src = &b->h_cap_args[b->cap_used++];
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_args, src, sizeof(a), hipMemcpyHostToDevice, st));
     const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0;
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);
     const int nwv = cur_nw_variant(b->e);

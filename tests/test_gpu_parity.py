@@ -136,6 +136,43 @@ def test_one_frame_steps_for_small_batches_match_oracle(n, blob_f32, hip_lib):
     b.close()
 
 
+def test_a_step_captured_in_a_hip_graph_replays_bit_exactly(blob_f32, hip_lib):
+    """the device-pointer call is enqueue-only; round 5 makes it CAPTURABLE: one real-time step (frame kernels + sample kernel + the copy of the
+    sample kernel's argument block, taken from a pinned pool that outlives the call) is captured into a HIP graph on a side stream and
+    replayed frame after frame on a static feature / PCM buffer -- every replay must equal the oracle, and the batch must stay usable"""
+    import torch
+    n, T = 64, 6
+    feats = feats_for(range(8800, 8800 + n), T)
+    want, _ = oracle_run(blob_f32, feats[:6])
+    dev = torch.device("cuda:0")
+    b = api.LPCNetBatch(n, blob_f32)
+    b.streams_per_workgroup = 4
+    d_feat = torch.zeros((n, 36), dtype=torch.float32, device=dev)
+    d_pcm = torch.zeros((n, 160), dtype=torch.int16, device=dev)
+    s = torch.cuda.Stream()
+    out = []
+    with torch.cuda.stream(s):                                   # frame 0 eagerly (first launch: function attributes, code-object load)
+        d_feat.copy_(torch.from_numpy(np.ascontiguousarray(feats[:, 0])))
+        b.synthesize_device(d_feat.data_ptr(), 36, d_pcm.data_ptr(), 1, s.cuda_stream)
+        s.synchronize()
+        out.append(d_pcm.cpu().numpy().copy())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        b.synthesize_device(d_feat.data_ptr(), 36, d_pcm.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+    for t in range(1, T):
+        d_feat.copy_(torch.from_numpy(np.ascontiguousarray(feats[:, t])))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        out.append(d_pcm.cpu().numpy().copy())
+    got = np.concatenate(out, axis=1)
+    assert np.array_equal(got[:6], want)
+    st = b.get_state(5)                                          # host-side access after the replays: the batch's own bookkeeping is intact
+    assert st.frame_count == T
+    del g
+    b.close()
+
+
 def test_streaming_calls_equal_one_call_and_chunking(blob_f32, hip_lib):
     """state carried across calls; n_frames above the internal 100-frame chunk; single-frame calls."""
     n, T = 2, 104
