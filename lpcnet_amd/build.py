@@ -90,8 +90,9 @@ def build(force=False, verbose=True, prof=False):
     jobs = [([HIPCC] + HIP_FLAGS + pf + extra + ["-c", os.path.join(CSRC, "engine.hip"), "-o", os.path.join(objdir, "engine.o")])]
     for sv in (1, 2, 4):
         jobs.append([HIPCC] + HIP_FLAGS + pf + extra + [f"-DLPCN_S={sv}", "-c", os.path.join(CSRC, "sample_variants.hip"), "-o", os.path.join(objdir, f"sample_s{sv}.o")])
+    jobs.append([HIPCC] + HIP_FLAGS + pf + extra + ["-c", os.path.join(CSRC, "sample_x2.hip"), "-o", os.path.join(objdir, "sample_x2.o")])
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=5) as ex:
         list(ex.map(run, jobs))
     objs += [j[-1] for j in jobs]
     for c in ("api.c", "model_pack.c"):
@@ -117,7 +118,7 @@ def build_small_registry(verbose=False):
     o = os.path.join(objdir, "api_smallreg.o")
     cmds = [["gcc"] + C_FLAGS + ["-DLPCN_MAX_MODELS=4", "-DLPCN_MAX_RESIDENT=2", f'-DLPCN_SOURCE_HASH="{h_src}-smallreg"', f'-DLPCN_DEVICE_SOURCE_HASH="{h_dev}"',
                                  "-c", os.path.join(CSRC, "api.c"), "-o", o],
-            [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + [os.path.join(objdir, f) for f in ("engine.o", "sample_s1.o", "sample_s2.o", "sample_s4.o")]
+            [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + [os.path.join(objdir, f) for f in ("engine.o", "sample_s1.o", "sample_s2.o", "sample_s4.o", "sample_x2.o")]
             + [o, os.path.join(objdir, "model_pack.o"), "-lpthread", "-lm"]]
     for c in cmds:
         if verbose:

@@ -198,6 +198,11 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     };
     if ((rc = upload_gru_a(m, a, nwv))) return fail(rc);
 #define UP(T, field, src, count) if ((rc = upload<T>(e, &a.field, src, count))) return fail(rc)
+    if (!m->is_int8) {                                       // the tables in the blob's own [256][1152] order: the start-value pass of the two-group kernel
+        UP(float, emb_nat_sig, m->emb_sig, (size_t)256 * LPCN_ROWS_A);
+        UP(float, emb_nat_pred, m->emb_pred, (size_t)256 * LPCN_ROWS_A);
+        UP(float, emb_nat_exc, m->emb_exc, (size_t)256 * LPCN_ROWS_A);
+    }
     UP(float, a_bias1, m->a_bias + LPCN_ROWS_A, LPCN_ROWS_A);
     UP(float, a_diag, m->a_diag, LPCN_ROWS_A);
     if (m->is_int8) {
@@ -355,6 +360,14 @@ static int device_cus(const lpcn_engine *e)
 // items per lane of the GRU-A image the engine's current arithmetic runs on
 static int cur_nw_variant(const lpcn_engine *e) { return (e->fast && e->has_fast_image) ? e->nw_variant_fast : e->nw_variant; }
 static bool pack2_available(const lpcn_engine *e) { return e->is_int8 && cur_nw_variant(e) <= 32; }
+// Two groups of four float streams per workgroup, half a step apart (sample_kernel_x2.hip.h): float blobs, PARITY arithmetic, dense GRU-B input
+// matrix, <= 32 items per lane.  b->S == 8 selects it.
+static bool x2_available(const lpcn_engine *e)
+{
+    const char *off = getenv("LPCNET_HIP_NO_X2");            // tools / tests: "1" = never
+    if (off && *off == '1') return false;
+    return !e->is_int8 && !e->fast && e->sargs.b_dense && e->nw_variant <= 32;
+}
 static bool use_pack2(const lpcn_engine *e, int n, int S)
 {
     const char *force = getenv("LPCNET_HIP_PACK2");          // tools / tests: "0" never, "1" whenever the variant exists
@@ -380,6 +393,12 @@ static int auto_streams_per_wg(const lpcn_engine *e, int n)
         if (use_pack2(e, n, S)) t = (float)((wgs + 2 * cus - 1) / (2 * cus)) * pair[k];
         else t = (float)((wgs + cus - 1) / cus) * step[k];
         if (k == 0 || t < best_t) { best = S; best_t = t; }
+    }
+    if (x2_available(e)) {                                   // eight streams per workgroup: a round of the two-group kernel (us per sample step)
+        static const float step_x2 = 12.6f;
+        const int wgs = (n + 7) / 8;
+        const float t = (float)((wgs + cus - 1) / cus) * step_x2;
+        if (t < best_t) { best = 8; best_t = t; }
     }
     return best;
 }
@@ -488,7 +507,8 @@ extern "C" int lpcn_batch_dev_set_streams_per_wg(lpcn_batch_dev *b, int s)
 {
     b->S_auto = s == 0;
     if (s == 0) { s = auto_streams_per_wg(b->e, b->n); b->tuned = false; }
-    if (s != 1 && s != 2 && s != 4) { snprintf(g_err, sizeof(g_err), "streams per workgroup must be 1, 2 or 4"); return LPCN_E_ARG; }
+    if (s == 8 && !x2_available(b->e)) { snprintf(g_err, sizeof(g_err), "eight streams per workgroup need a float blob with a dense GRU-B matrix and <= 32 items per lane, PARITY arithmetic"); return LPCN_E_ARG; }
+    if (s != 1 && s != 2 && s != 4 && s != 8) { snprintf(g_err, sizeof(g_err), "streams per workgroup must be 1, 2, 4 or 8"); return LPCN_E_ARG; }
     b->S = s;
     b->pack2 = use_pack2(b->e, b->n, b->S);
     return 0;
@@ -518,6 +538,8 @@ extern "C" int lpcn_batch_dev_sync(lpcn_batch_dev *b)
 extern "C" int lpcn_launch_sample_s1(int nw, int is_int8, int flags, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
 extern "C" int lpcn_launch_sample_s2(int nw, int is_int8, int flags, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
 extern "C" int lpcn_launch_sample_s4(int nw, int is_int8, int flags, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);
+extern "C" int lpcn_launch_sample_x2(int nw, int grid, int lds, hipStream_t st, const LpcnSampleArgs *d_args);      // sample_x2.hip: two groups of four streams
+extern "C" int lpcn_x2_lds_bytes(int nb_b);
 
 // one chunk of the per-sample kernel; cond_a/cond_b/lpc for the chunk are already in the batch buffers
 static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t pcm_stride, int n_frames,
@@ -541,11 +563,14 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
         src = &b->h_cap_args[b->cap_used++];
     }
     HIP_TRY(hipMemcpyAsync(b->d_args, src, sizeof(a), hipMemcpyHostToDevice, st));
-    const int grid = (b->n + b->S - 1) / b->S, i8 = b->e->is_int8 ? 1 : 0;
+    const int i8 = b->e->is_int8 ? 1 : 0;
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);
     const int nwv = cur_nw_variant(b->e);
     int lds = 0, rc = 0;
+    if (b->S == 8 && !x2_available(b->e)) { b->S = 4; b->pack2 = false; }      // (the arithmetic flavour changed under a pinned value)
+    const int grid = (b->n + b->S - 1) / b->S;
     switch (b->S) {
+    case 8: lds = lpcn_x2_lds_bytes(b->e->nb_b); rc = lpcn_launch_sample_x2(nwv, grid, lds, st, b->d_args); break;
     case 1: lds = lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(nwv, i8, fast, grid, lds, st, b->d_args); break;
     case 2: lds = lpcn::Lds<2>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s2(nwv, i8, fast, grid, lds, st, b->d_args); break;
     default: lds = lpcn::Lds<4>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s4(nwv, i8, fast, grid, lds, st, b->d_args); break;
@@ -597,7 +622,8 @@ static int autotune_streams_per_wg(lpcn_batch_dev *b, hipStream_t st)
     const bool keepP = b->pack2;
     int best = keepS;
     float best_ms = -1.f;
-    for (int S = 1; S <= 4; S *= 2) {
+    for (int S = 1; S <= 8; S *= 2) {
+        if (S == 8 && (!x2_available(b->e) || b->n <= 4)) break;
         b->S = S; b->pack2 = use_pack2(b->e, b->n, S);
         float ms = -1.f, ms1 = 0.f;
         for (int pass = 0; pass < 7 && !rc; ++pass) {          // warm-up (1 frame), then three pairs of (1 frame, nf frames): the smallest difference

@@ -107,6 +107,7 @@ struct LpcnSampleArgs {
     unsigned long long *prof;                       // optional: [8] shader-clock totals per phase, workgroup 0 wave 0
     const uint32_t *fc_wh;                          // FAST sub-option: dual-FC weights as fp16 pairs [256][2][8] (BASELINE config 4: "fp16 dual-FC")
     int fc_f16;                                     // non-zero: the tree phase runs on fc_wh with v_dot2_f32_f16 (FAST only)
+    const float *emb_nat_sig, *emb_nat_pred, *emb_nat_exc;      // [256][1152]: the embedding tables in the blob's own row order (float blobs; sample_kernel_x2.hip.h)
 };
 
 #ifndef LPCN_ENABLE_PROF
