@@ -1345,6 +1345,16 @@ int lpcnet_hip_check_model(const unsigned char *data, int len, int *info)
             lpcn_model_release(&f);
         }
     }
+    if (!st && !m.is_int8) {                             /* the two-group kernel's own GRU-A packing (float blobs that fit it) */
+        lpcn_model_host f;
+        if (lpcn_model_pack_x2(&m, &f) == 0) {
+            f.pk_b_w = m.pk_b_w; f.pk_b_start = m.pk_b_start; f.pk_b_blk = m.pk_b_blk;
+            const int sf = lpcn_model_selftest(&f);
+            if (sf) st = 200 + sf;
+            f.pk_b_w = NULL; f.pk_b_start = NULL; f.pk_b_blk = NULL;
+            lpcn_model_release(&f);
+        }
+    }
     if (info) { info[0] = m.is_int8; info[1] = m.nb_a; info[2] = m.nb_b; info[3] = m.nw; info[4] = m.nb_b_padded; info[5] = st; }
     lpcn_model_release(&m);
     if (st) { set_err("internal error: device packing inconsistent with blob"); return -1; }

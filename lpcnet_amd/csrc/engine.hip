@@ -47,6 +47,9 @@ struct lpcn_engine {
     LpcnSampleArgs sargs_fast{};   // the same with the FAST arithmetic's own GRU-A packing (int8 blobs: dealt without candidate heads)
     bool has_fast_image = false;
     int nw_variant_fast = 0;
+    LpcnSampleArgs sargs_x2{};     // the same with the two-group kernel's own GRU-A packing (float blobs; model_pack.c: lpcn_model_pack_x2)
+    bool has_x2_image = false;
+    int nw_variant_x2 = 0;
     LpcnFrameModel fmodel{};
     lpcn::DecodeTables dec{};      // codec path: VQ codebooks + pitch table (set by lpcn_engine_set_codebooks)
     bool has_codebooks = false;
@@ -190,9 +193,11 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
         UPD(int, a_bound, bound, LPCN_WAVES * 4);
         UPD(int, a_allh, allh, LPCN_WAVES * 3);
         UPD(int, a_head, mm->pk_a_head, LPCN_WAVES);
-        UPD(float, emb_sig, mm->pk_emb[0], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
-        UPD(float, emb_pred, mm->pk_emb[1], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
-        UPD(float, emb_exc, mm->pk_emb[2], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+        if (mm->pk_emb[0]) {                                  // (the two-group kernel's image has no lane-ordered tables)
+            UPD(float, emb_sig, mm->pk_emb[0], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+            UPD(float, emb_pred, mm->pk_emb[1], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+            UPD(float, emb_exc, mm->pk_emb[2], (size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS);
+        }
 #undef UPD
         return 0;
     };
@@ -242,6 +247,26 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
 #undef UP
     a.nb_b = m->nb_b_padded;
     a.b_dense = m->b_dense;
+    if (!m->is_int8 && m->b_dense && !getenv("LPCNET_HIP_NO_X2_IMAGE")) {
+        // the two-group kernel (eight float streams per workgroup) runs on its own dealing of GRU-A: chains on waves 0, 1, rows on waves 2..7
+        lpcn_model_host mx;
+        if (lpcn_model_pack_x2(m, &mx) == 0) {
+            static const int variants_x2[] = {24, 28, 30, 32, 0};
+            int nwx = 0;
+            for (const int *v = variants_x2; *v; ++v) if (mx.nw <= *v) { nwx = *v; break; }
+            mx.pk_b_w = m->pk_b_w; mx.pk_b_start = m->pk_b_start; mx.pk_b_blk = m->pk_b_blk;      // (the check reads GRU-B's packing too: shared)
+            const int stx = lpcn_model_selftest(&mx);
+            mx.pk_b_w = nullptr; mx.pk_b_start = nullptr; mx.pk_b_blk = nullptr;
+            if (nwx && stx == 0) {
+                e->sargs_x2 = e->sargs;
+                rc = upload_gru_a(&mx, e->sargs_x2, nwx);
+                e->nw_variant_x2 = nwx;
+                e->has_x2_image = rc == 0;
+            }
+            lpcn_model_release(&mx);
+            if (rc) return fail(rc);
+        }
+    }
     {   // the FAST arithmetic's own GRU-A image where its best dealing is not PARITY's (int8 blobs)
         lpcn_model_host mf;
         const int pf = getenv("LPCNET_HIP_NO_FAST_IMAGE") ? 1 : lpcn_model_pack_fast(m, &mf);
@@ -366,7 +391,7 @@ static bool x2_available(const lpcn_engine *e)
 {
     const char *off = getenv("LPCNET_HIP_NO_X2");            // tools / tests: "1" = never
     if (off && *off == '1') return false;
-    return !e->is_int8 && !e->fast && e->sargs.b_dense && e->nw_variant <= 32;
+    return e->has_x2_image && !e->fast;
 }
 static bool use_pack2(const lpcn_engine *e, int n, int S)
 {
@@ -395,7 +420,7 @@ static int auto_streams_per_wg(const lpcn_engine *e, int n)
         if (k == 0 || t < best_t) { best = S; best_t = t; }
     }
     if (x2_available(e)) {                                   // eight streams per workgroup: a round of the two-group kernel (us per sample step)
-        static const float step_x2 = 12.6f;
+        static const float step_x2 = 13.9f;
         const int wgs = (n + 7) / 8;
         const float t = (float)((wgs + cus - 1) / cus) * step_x2;
         if (t < best_t) { best = 8; best_t = t; }
@@ -545,7 +570,8 @@ extern "C" int lpcn_x2_lds_bytes(int nb_b);
 static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t pcm_stride, int n_frames,
                          int preload, bool fc_from_frames)
 {
-    LpcnSampleArgs a = (b->e->fast && b->e->has_fast_image) ? b->e->sargs_fast : b->e->sargs;
+    if (b->S == 8 && !x2_available(b->e)) { b->S = 4; b->pack2 = false; }      // (the arithmetic flavour changed under a pinned value)
+    LpcnSampleArgs a = b->S == 8 ? b->e->sargs_x2 : ((b->e->fast && b->e->has_fast_image) ? b->e->sargs_fast : b->e->sargs);
     a.n_streams = b->n; a.n_frames = n_frames; a.preload = preload; a.frame_len = b->frame_len;
     a.fc_advance = fc_from_frames ? 1 : 0;
     a.cond_a = b->d_cond_a; a.cond_b = b->d_cond_b; a.lpc = b->d_lpc;
@@ -567,10 +593,9 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);
     const int nwv = cur_nw_variant(b->e);
     int lds = 0, rc = 0;
-    if (b->S == 8 && !x2_available(b->e)) { b->S = 4; b->pack2 = false; }      // (the arithmetic flavour changed under a pinned value)
     const int grid = (b->n + b->S - 1) / b->S;
     switch (b->S) {
-    case 8: lds = lpcn_x2_lds_bytes(b->e->nb_b); rc = lpcn_launch_sample_x2(nwv, grid, lds, st, b->d_args); break;
+    case 8: lds = lpcn_x2_lds_bytes(b->e->nb_b); rc = lpcn_launch_sample_x2(b->e->nw_variant_x2, grid, lds, st, b->d_args); break;
     case 1: lds = lpcn::Lds<1>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s1(nwv, i8, fast, grid, lds, st, b->d_args); break;
     case 2: lds = lpcn::Lds<2>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s2(nwv, i8, fast, grid, lds, st, b->d_args); break;
     default: lds = lpcn::Lds<4>::total(b->e->nb_b, b->e->is_int8); rc = lpcn_launch_sample_s4(nwv, i8, fast, grid, lds, st, b->d_args); break;

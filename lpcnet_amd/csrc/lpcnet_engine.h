@@ -61,6 +61,12 @@ extern "C" {
 #ifndef LPCN_DEAL_EH_I8
 #define LPCN_DEAL_EH_I8 22
 #endif
+/* the two-group float kernel (sample_kernel_x2.hip.h): GRU-B's chains -- one stream each -- run on waves 0 .. LPCN_X2_CHAIN_WAVES - 1; waves LPCN_X2_P0_FIRST .. 7
+ * carry one candidate slot each (its head runs in the chains' shadow) and run the start-value pass, wave LPCN_X2_P0_FIRST also leads the streams; at most
+ * LPCN_X2_NW_MAX register-resident items per lane */
+#define LPCN_X2_CHAIN_WAVES 4
+#define LPCN_X2_P0_FIRST 4
+#define LPCN_X2_NW_MAX 32
 #define LPCN_DEAL_EH_FAST_I8 0 /* head length of the FAST arithmetic's own image of int8 blobs (model_pack.c: lpcn_model_pack_fast) */
 
 typedef struct lpcn_model_host {
@@ -106,6 +112,7 @@ typedef struct lpcn_model_host {
  * malformed / incomplete blob (same condition under which lpcnet_load_model returns -1). */
 int  lpcn_model_parse(lpcn_model_host *m, const unsigned char *blob, int len);
 void lpcn_model_release(lpcn_model_host *m);
+int  lpcn_model_pack_x2(const lpcn_model_host *m, lpcn_model_host *f);     /* 0: f holds the two-group kernel's own GRU-A packing; -1: the model does not fit it */
 int  lpcn_model_pack_fast(const lpcn_model_host *m, lpcn_model_host *f);   /* 1: FAST shares PARITY's image; 0: f holds FAST's own GRU-A packing */
 /* re-expand the packings and compare them with the blob (0 = consistent) */
 int  lpcn_model_selftest(const lpcn_model_host *m);

@@ -228,7 +228,7 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
             if (m->is_int8 && !for_fast && !(hw && *hw)) dp->hmask = LPCN_DEAL_HMASK_I8;      /* (FAST's own image has no heads and keeps the dealing it was tuned with) */
             if (m->is_int8 && hm && *hm) dp->hmask = (unsigned)strtoul(hm, NULL, 0) & 0xFFu;
         }
-        if (for_fast) {                                /* FAST int8 (GRU-B split over all waves: no shadow to hide a head in): 0 / 6 / 14 -> 184 / 163 / 167 M */
+        if (for_fast == 1) {                           /* FAST int8 (GRU-B split over all waves: no shadow to hide a head in): 0 / 6 / 14 -> 184 / 163 / 167 M */
             const char *ehf = getenv("LPCN_DEAL_EH_FAST");
             dp->eh = (ehf && *ehf) ? atoi(ehf) : LPCN_DEAL_EH_FAST_I8;
         }
@@ -338,10 +338,14 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
             for (int sl = 0; sl < NSLOT; sl++) { wave_of[sl] = newid[w2[sl]]; items[wave_of[sl]] += slot_max[sl]; }
         }
     }
+    /* (for_fast == 2, the two-group kernel's image: the SAME dealing.  Its start values come from an element-wise pass on waves 4..7, so a row may
+     * live on any wave, and a dealing of its own was built -- longest candidate slots on waves 4..7, everything else longest-first to the cheapest
+     * wave of a cost model fitted to its phase clocks -- and measured: 135.9 M samples/s against 145.6 M with this one, and tools/deal_search.py
+     * --x2 found no neighbour of this one that is faster (round 6; LPCN_DEAL_FORCE_X2 forces a map for such measurements).) */
     {   /* tools (tools/deal_search.py): LPCN_DEAL_FORCE = "w0,w1,...,w17" puts slot i (candidate slots first, both kinds by descending
          * length) on wave wi -- a dealing found by MEASUREMENT can be compared with the cost model's; LPCN_DEAL_PRINT=1 prints the map */
-        const char *force = getenv("LPCN_DEAL_FORCE");
-        if (force && *force && deal2 && !for_fast) {
+        const char *force = getenv(for_fast == 2 ? "LPCN_DEAL_FORCE_X2" : "LPCN_DEAL_FORCE");
+        if (force && *force && deal2 && for_fast != 1) {
             int wf[NSLOT], n = 0, cnt[LPCN_WAVES] = {0}, sum[LPCN_WAVES] = {0}, ok = 1;
             for (const char *q = force; *q && n < NSLOT; n++) { wf[n] = atoi(q); while (*q && *q != ',') q++; if (*q) q++; }
             for (int sl = 0; ok && sl < NSLOT; sl++) {
@@ -359,8 +363,8 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
             else fprintf(stderr, "LPCN_DEAL_FORCE ignored (needs %d waves 0..%d, <= %d slots and one candidate slot per wave, <= 40 items)\n", NSLOT, LPCN_WAVES - 1, LPCN_MAX_SLOTS);
         }
         const char *pr = getenv("LPCN_DEAL_PRINT");
-        if (pr && *pr == '1' && !for_fast) {
-            fprintf(stderr, "LPCN_DEAL slots (length:wave%s):", m->is_int8 ? ", int8" : "");
+        if (pr && *pr == '1' && for_fast != 1) {
+            fprintf(stderr, "LPCN_DEAL slots (length:wave%s%s):", m->is_int8 ? ", int8" : "", for_fast == 2 ? ", two-group kernel" : "");
             for (int sl = 0; sl < NSLOT; sl++) fprintf(stderr, " %s%d:%d", slot_allh[sl] ? "c" : "", slot_max[sl], wave_of[sl]);
             fprintf(stderr, "\n");
         }
@@ -430,6 +434,7 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
     /* Embedding tables re-ordered to the lane layout: E'[level][slot 0..2][thread 0..511] holds the
      * table entry of the row thread t owns in slot k, so the per-sample gather of one slot is a
      * fully coalesced 256-byte read per wave (2 KB per workgroup) per table and stream. */
+    if (for_fast == 2) return 0;                    /* (the two-group kernel reads the tables in the blob's own row order) */
     const float *src[3] = {m->emb_sig, m->emb_pred, m->emb_exc};
     for (int tb = 0; tb < 3; tb++) {
         float *dst = (float *)calloc((size_t)256 * LPCN_MAX_SLOTS * LPCN_WG_THREADS, sizeof(float));
@@ -558,6 +563,21 @@ int lpcn_model_pack_fast(const lpcn_model_host *m, lpcn_model_host *f)
     return 0;
 }
 
+/* The two-group kernel's own dealing of GRU-A (float blobs; see pack_gru_a).  `f` becomes a shallow copy of `m` with its own pk_a_* arrays
+ * (no lane-ordered embedding tables); returns 0, or -1 when the model does not fit (more than LPCN_X2_NW_MAX items on a lane, int8 blob).
+ * Release with lpcn_model_release(f). */
+int lpcn_model_pack_x2(const lpcn_model_host *m, lpcn_model_host *f)
+{
+    if (m->is_int8) return -1;
+    *f = *m;
+    f->pk_a_w = NULL; f->pk_a_wq = NULL; f->pk_a_blk = NULL; f->pk_a_row = NULL;
+    f->pk_b_w = NULL; f->pk_b_wq = NULL; f->pk_b_start = NULL; f->pk_b_blk = NULL;
+    for (int i = 0; i < 3; i++) f->pk_emb[i] = NULL;
+    const int rc = pack_gru_a(f, 2);
+    if (rc || f->nw > LPCN_X2_NW_MAX) { lpcn_model_release(f); return -1; }
+    return 0;
+}
+
 void lpcn_model_release(lpcn_model_host *m)
 {
     free(m->pk_a_w); free(m->pk_a_wq); free(m->pk_b_wq); free(m->pk_a_blk); free(m->pk_a_row);
@@ -662,7 +682,7 @@ int lpcn_model_selftest(const lpcn_model_host *m)
                 seen[row] = 1;
                 if (m->pk_a_allh[wv][k] && row < 2 * LPCN_N_A) { rc = 3; goto done; }
                 const int head = k == 0 ? m->pk_a_head[wv] : 0;       /* slot 0's early items sit end-aligned */
-                if ((wv < LPCN_WAVES / 2 && m->pk_a_head[wv]) || head < 0 || head > LPCN_EARLY_MAX || m->pk_a_bound[wv][LPCN_MAX_SLOTS] + m->pk_a_head[wv] > m->nw) { rc = 7; goto done; }
+                if ((wv < (m->pk_emb[0] ? LPCN_WAVES / 2 : LPCN_X2_P0_FIRST) && m->pk_a_head[wv]) || head < 0 || head > LPCN_EARLY_MAX || m->pk_a_bound[wv][LPCN_MAX_SLOTS] + m->pk_a_head[wv] > m->nw) { rc = 7; goto done; }
                 for (int jj = j0 - head; jj < j1; jj++) {
                     const int j = jj < j0 ? m->nw + (jj - j0) : jj;
                     size_t item = ((size_t)wv * m->nw + j) * 64 + lane;
@@ -677,8 +697,8 @@ int lpcn_model_selftest(const lpcn_model_host *m)
     }
     for (int r = 0; r < LPCN_ROWS_A; r++) if (!seen[r]) { rc = 4; goto done; }
     if (memcmp(dense, packed, sizeof(float) * LPCN_N_A * LPCN_ROWS_A)) { rc = 5; goto done; }
-    /* lane-ordered embedding tables */
-    {
+    /* lane-ordered embedding tables (the two-group kernel's image has none) */
+    if (m->pk_emb[0]) {
         const float *src[3] = {m->emb_sig, m->emb_pred, m->emb_exc};
         for (int tb = 0; tb < 3; tb++)
             for (int v = 0; v < 256; v += 51)

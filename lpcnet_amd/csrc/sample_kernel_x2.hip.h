@@ -27,10 +27,10 @@
 namespace lpcn {
 
 #ifndef LPCN_X2_LW
-#define LPCN_X2_LW 4            // the wave that leads the streams (tree walk, LPC predictor, mu-law): a head wave -- waves 0..3 start GRU-B's chains at once
+#define LPCN_X2_LW 4            // the wave that leads the streams (tree walk, LPC predictor, mu-law): a head wave (model_pack.c gives it the shortest candidate slot) -- waves 0..3 start GRU-B's chains at once
 #endif
 #ifndef LPCN_X2_TW
-#define LPCN_X2_TW 6            // the wave that draws the KISS99 thresholds
+#define LPCN_X2_TW 5            // the wave that draws the KISS99 thresholds
 #endif
 
 struct LdsX2 {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
 #pragma unroll
             for (int j = 0; j < 4; ++j) ((uint32_t *)ld)[s * 8 + 4 + j] = st->rng[j];
         }
-        if (tid < 2) { int *fl = (int *)(smem + tid * L::G_SZ + L::g_flag); fl[0] = 0; fl[1] = 0; }
+        if (tid < 2) { int *fl = (int *)(smem + tid * L::G_SZ + L::g_flag); fl[0] = 0; fl[1] = 0; fl[2] = 0; }
     }
     __syncthreads();
 
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
     bool liveP = false, liveQ = false;                       // per lane: leader lanes (their stream), threshold lanes
     int live_maskP = 0, live_maskQ = 0;                      // bit s: stream s of the group produces samples in its current frame
     int seqP = 0, seqQ = 0;                                  // samples opened so far, per group (identical in every wave)
+    int chnP = 0, chnQ = 0;                                  // GRU-B phases run so far, per group
     int smpP = 0, smpQ = 0, fP = 0, fQ = 0;                  // position of the group's NEXT P1 sample: sample within the frame, frame
     float lpc_tap = 0.f, prod_old = 0.f;                     // leader lanes: computed behind the tree of a group, used when its sample is finished
     auto row_shr1 = [](float v, float fill) __attribute__((always_inline)) {               // value of the previous lane of the 16-lane row; lane 0 gets `fill`
@@ -339,22 +340,24 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                 }
             }
         }
-        if (more && is_tw_lane && liveP) draw_thresholds(tid0 - 64 * TW);
+        if (more && is_tw_lane && liveP) { int t_ = tid0; LPCN_REMAT_V(t_); draw_thresholds(t_ - 64 * TW); }
 
         // ------------------------------------------------ group P enters a new frame --------------------
         if (new_frame) {
+            int tid = tid0;
+            LPCN_REMAT_V(tid);                                // (lane-derived values are rebuilt here: hoisted out of the half-step loop they are spilled)
+            const bool lw_ = (tid >> 6) == LW, twl_ = tid >= 64 * TW && tid < 64 * TW + S;
             __syncthreads();                                  // the leader's last sample of the previous frame
             if (fP > 0) {                                     // flush the finished frame's PCM (4 x 160 samples, coalesced)
                 auto *out = as_global_rw(Ap->pcm);
                 const size_t pstride = (size_t)Ap->pcm_stride;
-                for (int i = tid0; i < S * LPCN_FRAME_SIZE; i += LPCN_WG_THREADS) {
+                for (int i = tid; i < S * LPCN_FRAME_SIZE; i += LPCN_WG_THREADS) {
                     const int s = i / LPCN_FRAME_SIZE, k = i % LPCN_FRAME_SIZE;
                     if (S * p + s < n_valid && k < frame_len) out[(size_t)(s0 + S * p + s) * pstride + (size_t)(fP - 1) * LPCN_FRAME_SIZE + k] = pcm_p[i];
                 }
             }
             __syncthreads();                                  // (preload below overwrites the buffer)
             {
-                const int tid = tid0;
                 const auto *cb = as_global(Ap->cond_b), *lp = as_global(Ap->lpc);
                 float *const condb_p = (float *)(gp + L::g_condb);
                 if (tid < S * RB) condb_p[tid] = cb[((size_t)stream_of(S * p + tid / RB) * nf + fP) * RB + tid % RB];
@@ -362,8 +365,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                     const int i = tid - 256;
                     lpc_p[i] = lp[((size_t)stream_of(S * p + i / LPCN_LPC_ORDER) * nf + fP) * LPCN_LPC_ORDER + i % LPCN_LPC_ORDER];
                 }
-                if (is_lw || is_tw_lane) {
-                    const int lstream = stream_of(S * p + (is_lw ? LPCN_LROW : tid - 64 * TW));
+                if (lw_ || twl_) {
+                    const int lstream = stream_of(S * p + (lw_ ? (tid & 63) >> 4 : tid - 64 * TW));
                     const int fc_ref = Ap->fc_base ? as_global(Ap->fc_base)[lstream] : states[lstream].frame_count;
                     int fc = Ap->fc_advance ? fc_ref + fP + 1 : fc_ref;
                     if (fc > 1000) fc = 1000;
@@ -376,11 +379,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             }
             __syncthreads();                                  // lpc_p visible to the leaders
             ++seqP;
-            if (is_lw) {
-                open_sample(liveP, histP, histP * lpc_p[tid0 & 63], ((const int *)lead_p)[LPCN_LROW * 8 + 2], true);
+            if (lw_) {
+                open_sample(liveP, histP, histP * lpc_p[tid & 63], ((const int *)lead_p)[((tid & 63) >> 4) * 8 + 2], true);
                 publish_indices();
             }
-            if (is_tw_lane && liveP) draw_thresholds(tid0 - 64 * TW);
+            if (twl_ && liveP) draw_thresholds(tid - 64 * TW);
             __syncthreads();
             int lm = 0;
 #pragma unroll
@@ -415,6 +418,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             const float wk[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
             f2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
             f4 pv[4];
+            // (the four products of an item are issued back to back into four result tuples, then the sums.  Round 6 tried to software-pipeline the
+            // items by one -- the matrix-pipe instructions of item j + 1 between / behind the adds of item j, in one or in two sets of product
+            // registers: bit-exact and far slower, 113.8 vs 145.6 M samples/s -- an MFMA between dependent packed adds stalls both)
 #pragma unroll
             for (int c = 0; c < 4; ++c) pv[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(hk[c], wk[c], negz, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -432,6 +438,19 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
 
         const int lane = tid0 & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+        // this lane's dual-FC row (node = tid >> 1, channel = tid & 1) for group Q's tree, fetched behind the wave's items of P (it lands while the slots are closed)
+        float fcw[NB], fcb = 0.f, fcf = 0.f;
+        auto load_fc = [&]() __attribute__((always_inline)) {
+            int t_ = tid0;
+            LPCN_REMAT_V(t_);
+            const int node_ = t_ >> 1, chan_ = t_ & 1;
+            const auto *fcw_ptr = fc_w_s + node_ * 2 * NB + chan_ * NB;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
+            fcb = fc_b_s[chan_ * 256 + node_]; fcf = fc_f_s[chan_ * 256 + node_];
+        };
+        const uint32_t chcnt_q = lds_addr(gq + L::g_flag) + 8;   // arrival counter of Q's GRU-B chains (the tree of a wave must not start before all four have written their state)
+        if (q_chain) ++chnQ;
 
         // Order of an interval on one wave (round 6, third form.  The first ran P3 of Q, then all of P1 of P, and every wave then sat ~4 k clk behind
         // its own embedding gather; the second issued each wave's gather before Q's chain / heads and the 60 values in flight pushed GRU-A's weights
@@ -462,26 +481,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                 self(self, std::integral_constant<int, j + 1>{}, jend_c);
             }
         };
-        if (do_heads) {
-            hA_cur = gq + L::g_hA;
-            load_negz();
-            {
-                int r = LPCN_ROW(0);
-                LPCN_REMAT_V(r);
-                r = r < 0 ? 0 : r;
-                const int n = r - 2 * NA;
-                const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
-                const float *hT_q = (const float *)(gq + L::g_hT);
-#pragma unroll
-                for (int s = 0; s < S; ++s) acc[s] = bias + diag * hT_q[n * S + s];
-            }
-#pragma unroll
-            for (int j = 0; j < PF; ++j) if (J0 + j < NW) fetch_h(J0 + j);
-            head_step(head_step, std::integral_constant<int, J0>{}, std::integral_constant<int, JM>{});
-        }
-        LPCN_X2_PROF(3);
         const uint32_t p0cnt_p = flag_p + 4;                 // arrival counter of P's start-value pass
-        if (p_active && wave >= LPCN_WAVES / 2) {            // 3: P0 of group P on waves 4..7
+        // ---- 3: P0 of group P on waves 4..7, in five stages that are interleaved with the rest of Q's heads (the loads of a round land while head items run)
+        constexpr int CW = LPCN_X2_CHAIN_WAVES, P0W = LPCN_X2_P0_FIRST, NP0 = LPCN_WAVES - P0W;      // waves 0..3 carry GRU-B's chains (one stream each), waves 4..7 the heads and the start-value pass
+        static_assert(NP0 * 64 * 3 == 2 * NA && CW == S, "three rounds of the row waves' lanes cover GRU-A's update / reset rows");
+        const bool p0_wave = p_active && wave >= P0W;
+        uint32_t o_sig[S] = {}, o_pred[S] = {}, o_exc[S] = {}, o_cond[S] = {};      // byte offsets of the streams' table rows (scalar) -- the lane adds its row
+        int i0 = 0;
+        float ld[3][4 * S] = {};
+        auto p0_open = [&]() __attribute__((always_inline)) {
             int gi[S];
             wait_indices();
             {
@@ -490,8 +498,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
 #pragma unroll
                 for (int s = 0; s < S; ++s) gi[s] = __builtin_amdgcn_readfirstlane(v[s]);
             }
-            // byte offsets of the streams' table rows (scalar) -- the lane adds its row
-            uint32_t o_sig[S], o_pred[S], o_exc[S], o_cond[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 o_sig[s] = (uint32_t)(gi[s] & 0xFF) * (uint32_t)(RA * 4);
@@ -501,100 +507,135 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             }
             int t_ = tid0;
             LPCN_REMAT_V(t_);
-            // 256 lanes x 4.5 rounds cover the 1152 rows; the half round goes to waves 6, 7 (wave 4 also leads the streams)
-            const int i0 = ((((t_ >> 6) + 2) & 3) << 6) | (t_ & 63);
-            const bool fifth = wave >= 6;                    // (wave-uniform)
-            float ld[2][4 * S];
-            auto issue = [&](const int k, const int buf) __attribute__((always_inline)) {
-                const uint32_t rb = (uint32_t)(i0 + 256 * k) * 4u;
+            i0 = ((((t_ >> 6) + 2) & 3) << 6) | (t_ & 63);   // lane i0 of the 256 takes rows i0 + 256 k; the half round (k = 4: rows 1024..1151) goes to waves 6, 7
+        };
+        const bool fifth = wave >= 6;                        // (wave-uniform)
+        auto issue = [&](const int k, const int buf) __attribute__((always_inline)) {
+            const uint32_t rb = (uint32_t)(i0 + 256 * k) * 4u;
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    ld[buf][4 * s + 0] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)cond_a_s + (o_cond[s] + rb));
-                    ld[buf][4 * s + 1] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)emb_nat_sig + (o_sig[s] + rb));
-                    ld[buf][4 * s + 2] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)emb_nat_pred + (o_pred[s] + rb));
-                    ld[buf][4 * s + 3] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)emb_nat_exc + (o_exc[s] + rb));
-                }
-            };
-            auto reduce = [&](const int k, const int buf) __attribute__((always_inline)) {
-                const int r = i0 + 256 * k;
-                float g[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) g[s] = ((ld[buf][4 * s + 0] + ld[buf][4 * s + 1]) + ld[buf][4 * s + 2]) + ld[buf][4 * s + 3];      // src/nnet.c:487-489
-                if (k < 3) {                                 // update / reset rows: start value = (bias + diag*h) + input (src/nnet.c:431-440)
-                    const int n = r >= NA ? r - NA : r;
-                    const float2 bd = *(const float2 *)(sm_abias + 2 * r);
-                    const float4 hv = *(const float4 *)(hT_p + n * S);
-                    *(float4 *)(sm_pre_ur + r * S) = make_float4((bd.x + bd.y * hv.x) + g[0], (bd.x + bd.y * hv.y) + g[1], (bd.x + bd.y * hv.z) + g[2], (bd.x + bd.y * hv.w) + g[3]);
-                } else {                                     // candidate rows: the input part goes to the gate stage
-                    *(float4 *)(sm_inh + (r - 2 * NA) * S) = make_float4(g[0], g[1], g[2], g[3]);
-                }
-            };
-            issue(0, 0);
-            issue(1, 1);
-            reduce(0, 0);
-            issue(2, 0);
-            reduce(1, 1);
-            issue(3, 1);
-            reduce(2, 0);
-            if (fifth) issue(4, 0);
-            reduce(3, 1);
-            if (fifth) reduce(4, 0);
-            {                                                // the stores above are ahead of this add in the wave's LDS queue
-                int one = 1;
-                unsigned long long ex;
-                asm volatile("s_mov_b64 %0, exec\n\t"
-                             "s_mov_b64 exec, 1\n\t"
-                             "ds_add_u32 %1, %2\n\t"
-                             "s_mov_b64 exec, %0"
-                             : "=&s"(ex) : "v"(p0cnt_p), "v"(one) : "memory");
+            for (int s = 0; s < S; ++s) {
+                ld[buf][4 * s + 0] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)cond_a_s + (o_cond[s] + rb));
+                ld[buf][4 * s + 1] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)emb_nat_sig + (o_sig[s] + rb));
+                ld[buf][4 * s + 2] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)emb_nat_pred + (o_pred[s] + rb));
+                ld[buf][4 * s + 3] = *(const LPCN_GLOBAL float *)((const LPCN_GLOBAL char *)emb_nat_exc + (o_exc[s] + rb));
             }
-        }
-        LPCN_X2_PROF(4);
-        if (wave < S && q_chain) {
-            // GRU-B of stream `wave` of group Q: one lane per output row, 384 dependent adds per row in the reference's order; the state operand is a
-            // broadcast LDS read of the block the gate stage has written (grub_lds_loop_s4.inc, tools/gen_grub_asm.py --lds 4)
-            __builtin_amdgcn_s_setprio(3);
-            const int s = wave;
-            const int r = lane < RB ? lane : RB - 1;
-            const int g6 = r >> 3, ri = r & 7;
-            const float *const condb_q = (const float *)(gq + L::g_condb);
-            float zrh = sm_bbias[r] + condb_q[s * RB + r];                      // src/nnet.c:351
-            float rec = sm_bbias[RB + r];
+        };
+        auto reduce = [&](const int k, const int buf) __attribute__((always_inline)) {
+            const int r = i0 + 256 * k;
+            float g[S];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * hB_q[s * NB + j];
-            uint32_t wp32 = lds_addr(smem + L::bw + (sm_bstart[g6] * 8 + ri) * 16 + ((0x321100 >> (4 * g6)) & 15) * 128);
-            uint32_t hp32 = lds_addr(gq + L::g_hA + s * 16);
-            asm volatile(
+            for (int s = 0; s < S; ++s) g[s] = ((ld[buf][4 * s + 0] + ld[buf][4 * s + 1]) + ld[buf][4 * s + 2]) + ld[buf][4 * s + 3];      // src/nnet.c:487-489
+            if (k < 3) {                                     // update / reset rows: start value = (bias + diag*h) + input (src/nnet.c:431-440)
+                const int n = r >= NA ? r - NA : r;
+                const float2 bd = *(const float2 *)(sm_abias + 2 * r);
+                const float4 hv = *(const float4 *)(hT_p + n * S);
+                *(float4 *)(sm_pre_ur + r * S) = make_float4((bd.x + bd.y * hv.x) + g[0], (bd.x + bd.y * hv.y) + g[1], (bd.x + bd.y * hv.z) + g[2], (bd.x + bd.y * hv.w) + g[3]);
+            } else {                                         // candidate rows: the input part goes to the gate stage
+                *(float4 *)(sm_inh + (r - 2 * NA) * S) = make_float4(g[0], g[1], g[2], g[3]);
+            }
+        };
+        auto p0_arrive = [&]() __attribute__((always_inline)) {     // the stores above are ahead of this add in the wave's LDS queue
+            int one = 1;
+            unsigned long long ex;
+            asm volatile("s_mov_b64 %0, exec\n\t"
+                         "s_mov_b64 exec, 1\n\t"
+                         "ds_add_u32 %1, %2\n\t"
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(ex) : "v"(p0cnt_p), "v"(one) : "memory");
+        };
+        // The two kinds of waves take disjoint paths (so that the 64 registers GRU-B's assembly block names and the 48 loads of the start-value pass in
+        // flight never count against each other in the register allocation):
+        if (wave < CW) {
+            if (q_chain) {
+                // GRU-B of stream `wave` of group Q: one lane per output row, 384 dependent adds per row in the reference's order (src/nnet.c:326-372); the
+                // state operand is a broadcast LDS read of the block the gate stage has written (grub_lds_loop_s4.inc, tools/gen_grub_asm.py --lds 4).
+                // Round 6 measured three other forms of this link on the two-group kernel, all bit-exact, all slower (EXPERIMENTS.md): two streams per
+                // wave with 3 reads per block (92 clk per block), the same packed over the stream pair (90), all four streams on one wave with the
+                // products on the matrix pipe (135) -- per stream-block cheaper, but the interval waits for its longest chain.
+                __builtin_amdgcn_s_setprio(3);
+                const int s = wave;
+                int ln_ = tid0;
+                LPCN_REMAT_V(ln_);                           // (lane-derived addresses are rebuilt here: hoisted out of the loop they are spilled, and their scratch reloads sit in front of the chain)
+                ln_ &= 63;
+                const int r = ln_ < RB ? ln_ : RB - 1;
+                const int g6 = r >> 3, ri = r & 7;
+                const float *const condb_q = (const float *)(gq + L::g_condb);
+                float zrh = sm_bbias[r] + condb_q[s * RB + r];                  // src/nnet.c:351
+                float rec = sm_bbias[RB + r];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * hB_q[s * NB + j];
+                uint32_t wp32 = lds_addr(smem + L::bw + (sm_bstart[g6] * 8 + ri) * 16 + ((0x321100 >> (4 * g6)) & 15) * 128);
+                uint32_t hp32 = lds_addr(gq + L::g_hA + s * 16);
+                asm volatile(
 #include "grub_lds_loop_s4.inc"
-                : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
-            __builtin_amdgcn_s_setprio(0);
-            LPCN_X2_PROF(1);
-            // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
-            const float sg = lpcn_sigmoid(zrh + rec, sm_tansig);
-            int ln = tid0;
-            LPCN_REMAT_V(ln);
-            ln &= 15;
-            const float r_gate = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 + ln) << 2, __builtin_bit_cast(int, sg)));
-            const float hc = lpcn_tanh(zrh + rec * r_gate, sm_tansig);
-            const float hc_i = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((32 + ln) << 2, __builtin_bit_cast(int, hc)));
-            if (lane < NB) {
-                const float hold = hB_q[s * NB + lane];
-                const float hnew = sg * hold + (1.f - sg) * hc_i;
-                if ((live_maskQ >> s) & 1) hB_q[s * NB + lane] = hnew;
+                    : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
+                __builtin_amdgcn_s_setprio(0);
+                LPCN_X2_PROF(1);
+                // gates: rows [0,16) update, [16,32) reset, [32,48) candidate (src/nnet.c:362-371)
+                const int ln = ln_ & 15;
+                const float sg = lpcn_sigmoid(zrh + rec, sm_tansig);
+                const float r_gate = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((16 + ln) << 2, __builtin_bit_cast(int, sg)));
+                const float hc = lpcn_tanh(zrh + rec * r_gate, sm_tansig);
+                const float hc_i = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((32 + ln) << 2, __builtin_bit_cast(int, hc)));
+                if (ln_ < NB) {
+                    const float hold = hB_q[s * NB + ln_];
+                    const float hnew = sg * hold + (1.f - sg) * hc_i;
+                    if ((live_maskQ >> s) & 1) hB_q[s * NB + ln_] = hnew;
+                }
+                {                                            // (the store above is ahead of this add in the wave's LDS queue)
+                    int one = 1;
+                    unsigned long long ex;
+                    asm volatile("s_mov_b64 %0, exec\n\t"
+                                 "s_mov_b64 exec, 1\n\t"
+                                 "ds_add_u32 %1, %2\n\t"
+                                 "s_mov_b64 exec, %0"
+                                 : "=&s"(ex) : "v"(chcnt_q), "v"(one) : "memory");
+                }
+                LPCN_X2_PROF(2);
             }
-            LPCN_X2_PROF(2);
-        }
-        if (do_heads) {
-            head_step(head_step, std::integral_constant<int, JM>{}, std::integral_constant<int, NW>{});
-            int r = LPCN_ROW(0);
-            LPCN_REMAT_V(r);
-            if (r >= 0) {
-                float *c = pre_cell(r, gq);
+        } else {
+            if (do_heads) {
+                hA_cur = gq + L::g_hA;
+                load_negz();
+                {
+                    int r = LPCN_ROW(0);
+                    LPCN_REMAT_V(r);
+                    r = r < 0 ? 0 : r;
+                    const int n = r - 2 * NA;
+                    const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
+                    const float *hT_q = (const float *)(gq + L::g_hT);
 #pragma unroll
-                for (int s = 0; s < S; ++s) c[s] = acc[s];
+                    for (int s = 0; s < S; ++s) acc[s] = bias + diag * hT_q[n * S + s];
+                }
+#pragma unroll
+                for (int j = 0; j < PF; ++j) if (J0 + j < NW) fetch_h(J0 + j);
+                head_step(head_step, std::integral_constant<int, J0>{}, std::integral_constant<int, JM>{});
             }
+            LPCN_X2_PROF(3);
+            // all three rounds are issued at once (48 loads per lane in flight), the update / reset rows are reduced and announced first -- the row owners
+            // wait for those --, the candidate inputs, which only the gate stage behind the barrier needs, after the rest of the heads
+            if (p0_wave) {
+            p0_open();
+            issue(0, 0); issue(1, 1); issue(2, 2);
+            reduce(0, 0); reduce(1, 1); reduce(2, 2);
+            p0_arrive();
+            issue(3, 0);
+            if (fifth) issue(4, 1);
         }
-        LPCN_X2_PROF(3);
+            LPCN_X2_PROF(4);
+            if (do_heads) {
+                head_step(head_step, std::integral_constant<int, JM>{}, std::integral_constant<int, NW>{});
+                int r = LPCN_ROW(0);
+                LPCN_REMAT_V(r);
+                if (r >= 0) {
+                    float *c = pre_cell(r, gq);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) c[s] = acc[s];
+                }
+            }
+            if (p0_wave) { reduce(3, 0); if (fifth) reduce(4, 1); }
+            LPCN_X2_PROF(3);
+        }
 
         // ---------------------------------------------------------------- 5: P1 of group P ----
         if (p_active) {
@@ -602,7 +643,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             load_negz();
             {                                                // the start values of the update / reset rows and the candidate inputs come from P0
                 int v;
-                const int want = seqP * (LPCN_WAVES / 2);
+                const int want = seqP * NP0;
                 do {
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(p0cnt_p) : "memory");
                     v = __builtin_amdgcn_readfirstlane(v);
@@ -682,6 +723,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                 }
             };
             run_items(run_items, std::integral_constant<int, 0>{});
+            if (q_chain) load_fc();
             LPCN_X2_PROF(5);
             // close whichever slot is still open; slots that start exactly at the end have no items
             if (b1 >= jend) {
@@ -696,21 +738,50 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             }
             LPCN_X2_PROF(6);
         }
+        // ------------------------------------------------------------ P4 of group Q: dual-FC tree, all nodes at once (src/nnet.c:163-214) --
+        // Round 6: the tree runs on each wave BEHIND its own part of interval A, in front of the barrier -- a wave that is done early evaluates its nodes
+        // while others are still in their (latency-bound) items, instead of all eight saturating the vector units at once behind the barrier.
+        if (q_chain) {
+            if (!p_active) load_fc();
+            {
+                int v;
+                const int want = chnQ * S;
+                do {
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(chcnt_q) : "memory");
+                    v = __builtin_amdgcn_readfirstlane(v);
+                    if (v != want) __builtin_amdgcn_s_sleep(1);
+                } while (v != want);
+            }
+            int tid = tid0;
+            LPCN_REMAT_V(tid);
+            const int node = tid >> 1;
+            const int node_level = node > 0 ? 31 - __clz(node) : 0;
+            const float *const thr_q = (const float *)(gq + L::g_thr);
+            unsigned long long *const mask_q = (unsigned long long *)(gq + L::g_mask);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float sum = fcb;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) sum = sum + fcw[j] * hB_q[s * NB + j];                      // src/nnet.c:194-199
+                const float v = fcf * lpcn_tanh(sum, sm_tansig);
+                const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+                const float lg = v + vo;
+                const unsigned long long m = __ballot(thr_q[s * 8 + node_level] < lg) & (wave == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
+                if (lane == 0) mask_q[s * 8 + wave] = m;
+            }
+            // wave LW: the prediction terms of Q's next sample that do not involve the sample about to be drawn (src/lpcnet.c:252,262)
+            if (is_lw) {
+                lpc_tap = ((const float *)(gq + L::g_lpc))[tid & 63];
+                prod_old = row_shr1(histQ, 0.f) * lpc_tap;
+            }
+        }
+        LPCN_X2_PROF(9);
         __syncthreads();                                                       // B1
         LPCN_X2_PROF(7);
 
         // ================================================================ interval B ===========
         int tid = tid0;
         LPCN_REMAT_V(tid);
-        // this lane's dual-FC row (node = tid >> 1, channel = tid & 1) for group Q's tree; it lands while P's gate stage runs
-        const int node = tid >> 1, chan = tid & 1;
-        float fcw[NB], fcb = 0.f, fcf = 0.f;
-        if (q_chain) {
-            const auto *fcw_ptr = fc_w_s + node * 2 * NB + chan * NB;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) fcw[j] = fcw_ptr[j];
-            fcb = fc_b_s[chan * 256 + node]; fcf = fc_f_s[chan * 256 + node];
-        }
         // ------------------------------------------------------------ P2 of group P: GRU-A gates (src/nnet.c:441-447) --
         if (p_active) {
             constexpr int NI = NA * S, NQ = NI / LPCN_WG_THREADS;
@@ -741,29 +812,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             }
         }
         LPCN_X2_PROF(8);
-        // ------------------------------------------------------------ P4 of group Q: dual-FC tree, all nodes at once (src/nnet.c:163-214) --
-        if (q_chain) {
-            const int node_level = node > 0 ? 31 - __clz(node) : 0;
-            const float *const thr_q = (const float *)(gq + L::g_thr);
-            unsigned long long *const mask_q = (unsigned long long *)(gq + L::g_mask);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                float sum = fcb;
-#pragma unroll
-                for (int j = 0; j < NB; ++j) sum = sum + fcw[j] * hB_q[s * NB + j];                      // src/nnet.c:194-199
-                const float v = fcf * lpcn_tanh(sum, sm_tansig);
-                const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-                const float lg = v + vo;
-                const unsigned long long m = __ballot(thr_q[s * 8 + node_level] < lg) & (wave == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
-                if (lane == 0) mask_q[s * 8 + wave] = m;
-            }
-            // wave LW: the prediction terms of Q's next sample that do not involve the sample about to be drawn (src/lpcnet.c:252,262)
-            if (is_lw) {
-                lpc_tap = ((const float *)(gq + L::g_lpc))[tid & 63];
-                prod_old = row_shr1(histQ, 0.f) * lpc_tap;
-            }
-        }
-        LPCN_X2_PROF(9);
         __syncthreads();                                                       // B2
         LPCN_X2_PROF(10);
 
@@ -773,6 +821,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
         { const bool t = liveP; liveP = liveQ; liveQ = t; }
         { const int t = live_maskP; live_maskP = live_maskQ; live_maskQ = t; }
         { const int t = seqP; seqP = seqQ; seqQ = t; }
+        { const int t = chnP; chnP = chnQ; chnQ = t; }
         { const int t = smpP; smpP = smpQ; smpQ = t; }
         { const int t = fP; fP = fQ; fQ = t; }
         asm volatile("; LPCN_SAMPLE_LOOP_END" ::: "memory");

@@ -21,8 +21,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CTX = {}
 
 
+X2 = False          # --x2: the two-group kernel (eight streams per workgroup, 2048 streams, LPCN_DEAL_FORCE_X2)
+
+
 def bench(force, int8):
     """kernel rate (M samples/s) of a fresh 1024-stream batch dealt with `force` (None = the cost model's dealing), in process"""
+    if X2:
+        return bench_x2(force)
     import numpy as np
     sys.path.insert(0, ROOT)
     from lpcnet_amd import api, synth
@@ -51,12 +56,40 @@ def bench(force, int8):
     return 1024 * 10 * 160 / (best * 1e-3) / 1e6
 
 
+def bench_x2(force):
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from lpcnet_amd import api, synth
+    if "blob" not in _CTX:
+        _CTX["blob"] = synth.blob_bytes(synth.make_model())
+        base = np.stack([synth.make_features(1000 + s, 8) for s in range(16)])
+        _CTX["feats"] = np.ascontiguousarray(base[np.arange(2048) % 16])
+    if force is None:
+        os.environ.pop("LPCN_DEAL_FORCE_X2", None)
+    else:
+        os.environ["LPCN_DEAL_FORCE_X2"] = ",".join(str(w) for w in force)
+    try:
+        b = api.LPCNetBatch(2048, _CTX["blob"])
+        b.streams_per_workgroup = 8
+    except Exception:
+        return None
+    b.enable_timing(True)
+    b.synthesize(_CTX["feats"])
+    best = None
+    for _ in range(3):
+        b.synthesize(_CTX["feats"])
+        t = b.last_timing()[0]
+        best = t if best is None else min(best, t)
+    b.close()
+    return 2048 * 8 * 160 / (best * 1e-3) / 1e6
+
+
 def current_map(int8):
     env = dict(os.environ, LPCN_DEAL_PRINT="1")
     code = ("import sys; sys.path.insert(0, %r); from lpcnet_amd import api, synth; "
             "api.check_model(synth.blob_bytes(synth.make_model(flavour=%r)))" % (ROOT, "int8" if int8 else "float"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
-    m = re.search(r"LPCN_DEAL slots \(length:wave[^)]*\):(.*)", r.stderr)
+    m = re.search(r"LPCN_DEAL slots \(length:wave, two-group kernel\):(.*)" if X2 else r"LPCN_DEAL slots \(length:wave[^)]*\):(.*)", r.stderr)
     slots = m.group(1).split()
     return [(s.startswith("c"), int(s.lstrip("c").split(":")[0]), int(s.split(":")[1])) for s in slots]
 
@@ -73,13 +106,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--int8", action="store_true")
+    ap.add_argument("--x2", action="store_true", help="the two-group kernel's dealing (LPCN_DEAL_FORCE_X2, 2048 streams, eight per workgroup); candidate slots move too")
+    ap.add_argument("--start", default="", help="comma-separated start map instead of the model's dealing")
     a = ap.parse_args()
+    global X2
+    X2 = a.x2
     slots = current_map(a.int8)
     wv = [s[2] for s in slots]
     base = max(bench(None, a.int8), bench(None, a.int8))
+    if a.start:
+        wv = [int(x) for x in a.start.split(",")]
+        print("start map %s -> %.2f M (the model's dealing: %.2f M)" % (a.start, bench(wv, a.int8), base), flush=True)
+        base = max(bench(wv, a.int8), bench(wv, a.int8))
     print("model's dealing:", " ".join(("c" if c else "") + f"{n}:{w}" for c, n, w in slots), "-> %.2f M" % base, flush=True)
     best, best_v = list(wv), base
-    zr = [i for i, s in enumerate(slots) if not s[0]]
+    zr = [i for i, s in enumerate(slots) if not s[0] or X2]
     for rnd in range(a.rounds):
         improved = False
         cands = []

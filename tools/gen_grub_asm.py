@@ -180,6 +180,175 @@ def main_lds(S):
         print('"%s\\n\\t"' % ln)
 
 
+def main_lds2(S):
+    """GRU-B input mat-vec of TWO streams on one wave (round 6, sample_kernel_x2.hip.h): the lane's weight read of a block serves both streams, whose
+    state blocks -- neighbours in the [block][stream][4] layout -- arrive as two broadcast reads: three ds_read_b128 per block for two streams
+    instead of four, and two independent chains of dependent adds per lane, so the adds of the one sit in the latency of the other.  Per block: 8 v_add_f32
+    (two chains of four, interleaved), 4 v_pk_mul_f32 for the next block, 3 reads for the block RING - 1 ahead.  Every product and every sum is
+    rounded on its own, per stream in block order, columns 0..3 (src/vec.h:355-401).
+    Registers: product sets base+0..15 (set x {A, B} x 4), weight ring, state ring (A and B of a block side by side)."""
+    stride = 16 * S
+    ha_off = lambda p: p * stride + (p >> 2) * 16
+    R = RING
+    base = 256 - 16 - 12 * R
+    PS = [[base, base + 4], [base + 8, base + 12]]          # PS[set][stream]
+    WR = [base + 16 + 4 * i for i in range(R)]
+    HR = [[base + 16 + 4 * R + 8 * i, base + 16 + 4 * R + 8 * i + 4] for i in range(R)]      # HR[slot][stream]
+    CNT = 70
+    BPT = {3: 12, 4: 16, 6: 12}[R]
+    assert 96 % BPT == 0 and BPT % R == 0 and BPT % 2 == 0
+    LA = R - 1
+    rd = lambda slot, blk: [f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}",
+                            f"ds_read_b128 v[{HR[slot][0]}:{HR[slot][0] + 3}], %[hp] offset:{ha_off(blk)}",
+                            f"ds_read_b128 v[{HR[slot][1]}:{HR[slot][1] + 3}], %[hp] offset:{ha_off(blk) + 16}"]
+    def prod(pset, slot):
+        out = []
+        for st in range(2):
+            out += [f"v_pk_mul_f32 v[{PS[pset][st]}:{PS[pset][st] + 1}], v[{HR[slot][st]}:{HR[slot][st] + 1}], v[{WR[slot]}:{WR[slot] + 1}]",
+                    f"v_pk_mul_f32 v[{PS[pset][st] + 2}:{PS[pset][st] + 3}], v[{HR[slot][st] + 2}:{HR[slot][st] + 3}], v[{WR[slot] + 2}:{WR[slot] + 3}]"]
+        return out
+    def block(k):
+        pr = prod((k + 1) & 1, (k + 1) % R)
+        a = [[f"v_add_f32 %[z{'ab'[st]}], %[z{'ab'[st]}], v{PS[k & 1][st] + j}" for j in range(4)] for st in range(2)]
+        return rd((k + LA) % R, k + LA) + [f"s_waitcnt lgkmcnt({3 * (LA - 1)})",
+                a[0][0], a[1][0], pr[0], a[0][1], a[1][1], pr[1], a[0][2], a[1][2], pr[2], a[0][3], a[1][3], pr[3]]
+    lines = ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{CNT}, {96 // BPT}"]
+    for b in range(LA):
+        lines += rd(b % R, b)
+    lines += [f"s_waitcnt lgkmcnt({3 * (LA - 1)})"] + prod(0, 0)
+    lines += [".p2align 4"] + ["s_nop 0"] * PHASE
+    lines += ["1:"]
+    for k in range(BPT):
+        lines += block(k)
+    lines += [f"v_add_u32 %[wp], {BPT * 128}, %[wp]",
+              f"v_add_u32 %[hp], {ha_off(BPT)}, %[hp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py --lds2 %d --ring %d -- do not edit" % (S, R))
+    print("// operands: %[za], %[zb] float accumulators of streams s and s + 1 (in/out VGPRs), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of stream s's state, block 0 (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_LDS2_CLOBBERS")
+    print("#define LPCN_GRUB_LDS2_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
+def main_lds2p(S):
+    """GRU-B input mat-vec of TWO streams on one wave, PACKED over the stream pair (round 6, sample_kernel_x2.hip.h): the two accumulators live in one
+    register pair, a block is 4 v_pk_add_f32 (z_a, z_b) += (p_a, p_b) -- each half rounded on its own, per stream in block order, columns 0..3
+    (src/vec.h:355-401) -- and 4 v_pk_mul_f32 for the next block: (h_a, h_b)[column j] x the lane's weight w_j broadcast to both halves through
+    op_sel.  The state comes from the NEURON-major copy of the GRU-A state ([neuron][stream]: the pair of a column is 8 adjacent bytes, the four
+    columns of a block two ds_read2_b64), the weights as before: 3 LDS reads + 8 packed VALU instructions per block for two streams, against
+    2 + 6 for one stream in the single-stream loop and 3 + 12 in the unpacked two-stream loop (--lds2: 92 clk per block measured).
+    Registers: product sets base + 0..15, weight ring 4 per slot, state ring 8 per slot."""
+    R = RING
+    base = 256 - 16 - 12 * R
+    PS = [base, base + 8]                                    # PS[set] + 2 j = pair (stream a, stream b) of column j
+    WR = [base + 16 + 4 * i for i in range(R)]
+    HR = [base + 16 + 4 * R + 8 * i for i in range(R)]      # HR[slot] + 2 j = (h_a, h_b) of column j
+    CNT = 70
+    BPT = {3: 12, 4: 16, 6: 12}[R]
+    assert 96 % BPT == 0 and BPT % R == 0 and BPT % 2 == 0
+    LA = R - 1
+    stride = 4 * S * 4                                       # bytes per block in the [neuron][stream] layout
+    assert stride % 8 == 0 and (stride * (BPT + LA)) // 8 + 6 < 256
+    rd = lambda slot, blk: [f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}",
+                            f"ds_read2_b64 v[{HR[slot]}:{HR[slot] + 3}], %[hp] offset0:{blk * stride // 8} offset1:{blk * stride // 8 + 4 * S // 8 * 1}",
+                            f"ds_read2_b64 v[{HR[slot] + 4}:{HR[slot] + 7}], %[hp] offset0:{blk * stride // 8 + 2 * (4 * S // 8)} offset1:{blk * stride // 8 + 3 * (4 * S // 8)}"]
+    def prod(pset, slot):
+        out = []
+        for j in range(4):
+            wpair = WR[slot] + 2 * (j >> 1)
+            sel = "op_sel:[0,0] op_sel_hi:[1,0]" if (j & 1) == 0 else "op_sel:[0,1] op_sel_hi:[1,1]"
+            out.append(f"v_pk_mul_f32 v[{PS[pset] + 2 * j}:{PS[pset] + 2 * j + 1}], v[{HR[slot] + 2 * j}:{HR[slot] + 2 * j + 1}], v[{wpair}:{wpair + 1}] {sel}")
+        return out
+    def block(k):
+        pr = prod((k + 1) & 1, (k + 1) % R)
+        a = [f"v_pk_add_f32 %[z], %[z], v[{PS[k & 1] + 2 * j}:{PS[k & 1] + 2 * j + 1}]" for j in range(4)]
+        return rd((k + LA) % R, k + LA) + [f"s_waitcnt lgkmcnt({3 * (LA - 1)})", a[0], pr[0], a[1], pr[1], a[2], pr[2], a[3], pr[3]]
+    lines = ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{CNT}, {96 // BPT}"]
+    for b in range(LA):
+        lines += rd(b % R, b)
+    lines += [f"s_waitcnt lgkmcnt({3 * (LA - 1)})"] + prod(0, 0)
+    lines += [".p2align 4"] + ["s_nop 0"] * PHASE
+    lines += ["1:"]
+    for k in range(BPT):
+        lines += block(k)
+    lines += [f"v_add_u32 %[wp], {BPT * 128}, %[wp]",
+              f"v_add_u32 %[hp], {BPT * stride}, %[hp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)"]
+    print("// generated by tools/gen_grub_asm.py --lds2p %d --ring %d -- do not edit" % (S, R))
+    print("// operands: %[z] accumulator pair (stream s, stream s + 1) (in/out, 64-bit VGPR pair), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of (neuron 0, stream s) in the [neuron][stream] state (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_LDS2P_CLOBBERS")
+    print("#define LPCN_GRUB_LDS2P_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
+def main_lds4m(S):
+    """GRU-B input mat-vec of ALL FOUR streams of a group on ONE wave, products on the matrix pipe (round 6, sample_kernel_x2.hip.h).
+    What bounds the single-stream loop (--lds) is the wave's DS issue cadence -- ~25 clk per LDS instruction whatever its width
+    (profiles/r03_ubench_grub_scalar.txt), two reads per block -- not its 4 dependent adds.  So the reads have to serve more streams: lane (quad q,
+    i) fetches the 16 bytes of stream i's state block (the [block][stream][4] layout GRU-A's items use) and its own row's weights, and
+    v_mfma_f32_4x4x1 with C = -0.0 gives lane j, in register i, h_i[c] * w_j[c] rounded once -- bit for bit v_mul_f32's product
+    (tests: the matrix-pipe identity) -- for the four streams of the quad: TWO reads + 4 MFMA + 8 v_pk_add_f32 per block for four streams.  The sums
+    are two packed chains (streams 0 / 1, streams 2 / 3), each half rounded on its own, per stream in block order, columns 0..3 (src/vec.h:355-401);
+    the MFMAs of block b + 1 are issued between the adds of block b.
+    Registers: -0.0 quad, two product sets of 4 quads, weight ring, state ring."""
+    assert S == 4
+    stride = 16 * S
+    ha_off = lambda p: p * stride + (p >> 2) * 16
+    R = RING
+    base = 256 - 4 - 32 - 8 * R
+    NZ = base
+    PS = [base + 4, base + 20]                               # PS[set] + 4 c = product quad of column c (register i = stream i)
+    WR = [base + 36 + 4 * i for i in range(R)]
+    HR = [base + 36 + 4 * R + 4 * i for i in range(R)]
+    CNT = 70
+    BPT = {3: 12, 4: 16, 6: 12}[R]
+    assert 96 % BPT == 0 and BPT % R == 0 and BPT % 2 == 0
+    LA = R - 1
+    rd = lambda slot, blk: [f"ds_read_b128 v[{WR[slot]}:{WR[slot] + 3}], %[wp] offset:{blk * 128}",
+                            f"ds_read_b128 v[{HR[slot]}:{HR[slot] + 3}], %[hp] offset:{ha_off(blk)}"]
+    mf = lambda pset, slot, c: f"v_mfma_f32_4x4x1_16b_f32 v[{PS[pset] + 4 * c}:{PS[pset] + 4 * c + 3}], v{HR[slot] + c}, v{WR[slot] + c}, v[{NZ}:{NZ + 3}]"
+    def block(k):
+        out = rd((k + LA) % R, k + LA) + [f"s_waitcnt lgkmcnt({2 * (LA - 1)})"]
+        for c in range(4):
+            out += [mf((k + 1) & 1, (k + 1) % R, c),
+                    f"v_pk_add_f32 %[za], %[za], v[{PS[k & 1] + 4 * c}:{PS[k & 1] + 4 * c + 1}]",
+                    f"v_pk_add_f32 %[zb], %[zb], v[{PS[k & 1] + 4 * c + 2}:{PS[k & 1] + 4 * c + 3}]"]
+        return out
+    lines = ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{CNT}, {96 // BPT}"]
+    lines += [f"v_mov_b32 v{NZ + i}, 0x80000000" for i in range(4)]
+    for b in range(LA):
+        lines += rd(b % R, b)
+    lines += [f"s_waitcnt lgkmcnt({2 * (LA - 1)})"] + [mf(0, 0, c) for c in range(4)]
+    lines += [".p2align 4"] + ["s_nop 0"] * PHASE
+    lines += ["1:"]
+    for k in range(BPT):
+        lines += block(k)
+    lines += [f"v_add_u32 %[wp], {BPT * 128}, %[wp]",
+              f"v_add_u32 %[hp], {ha_off(BPT)}, %[hp]",
+              f"s_sub_u32 s{CNT}, s{CNT}, 1",
+              f"s_cmp_lg_u32 s{CNT}, 0",
+              "s_cbranch_scc1 1b",
+              "s_waitcnt lgkmcnt(0)",
+              "s_nop 7"]                                     # (the last trip's look-ahead MFMAs drain before the compiler's code may touch the clobbered registers)
+    print("// generated by tools/gen_grub_asm.py --lds4m %d --ring %d -- do not edit" % (S, R))
+    print("// operands: %[za] accumulator pair (streams 0, 1), %[zb] (streams 2, 3) (in/out, 64-bit VGPR pairs), %[wp] LDS byte address of the lane's row, block 0 (in/out VGPR), %[hp] LDS byte address of block 0 of stream (lane & 3) in the [block][stream][4] state (in/out VGPR)")
+    clob = [f"s{CNT}"] + [f"v{i}" for i in range(base, 256)]
+    print("#undef LPCN_GRUB_LDS4M_CLOBBERS")
+    print("#define LPCN_GRUB_LDS4M_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + ', "scc", "memory"')
+    for ln in lines:
+        print('"%s\\n\\t"' % ln)
+
+
 def main_rl(S):
     """GRU-B input mat-vec with the state operand in SGPRs again -- but filled from LDS, not from L2: ONE ds_read_b128 per 16
     blocks brings block b0 + L of the wave's stream to lane L (L < 16), and v_readlane_b32 moves the four values of the block
@@ -479,6 +648,12 @@ if __name__ == "__main__":
         main_prod(int(sys.argv[sys.argv.index("--prod") + 1]))
     elif "--rl" in sys.argv:
         main_rl(int(sys.argv[sys.argv.index("--rl") + 1]))
+    elif "--lds4m" in sys.argv:
+        main_lds4m(int(sys.argv[sys.argv.index("--lds4m") + 1]))
+    elif "--lds2p" in sys.argv:
+        main_lds2p(int(sys.argv[sys.argv.index("--lds2p") + 1]))
+    elif "--lds2" in sys.argv:
+        main_lds2(int(sys.argv[sys.argv.index("--lds2") + 1]))
     elif "--lds" in sys.argv:
         main_lds(int(sys.argv[sys.argv.index("--lds") + 1]))
     else:
