@@ -42,7 +42,13 @@ LPCNET_EXPORT int lpcnet_batch_reset(LPCNetBatch *b, int first, int count);
  * Copies in, runs, copies out, synchronises.  Returns 0 or a negative error code. */
 LPCNET_EXPORT int lpcnet_batch_synthesize(LPCNetBatch *b, const float *features, int feat_stride, short *pcm, int n_frames);
 /* Device-pointer synthesis: same layouts in device memory of the batch's device; only enqueues on
- * `hip_stream` (a hipStream_t; NULL = the batch's own stream).  lpcnet_batch_sync() waits. */
+ * `hip_stream` (a hipStream_t; NULL = the batch's own stream).  lpcnet_batch_sync() waits.
+ * Ordering: calls on different streams are ordered by the batch (an event chain); the batch's buffers and stream states are
+ * shared by all of them.  HIP graphs: the call may be issued on a stream that is being CAPTURED (nothing runs, nothing is
+ * allocated or synchronised; any number of launches may be captured, the kernels' arguments travel inside the graph).  The
+ * event chain does not see a capture, so REPLAYS of such a graph are not ordered against other work on the same batch --
+ * eager calls, other graphs, state export / import, reset: put them on the replay's stream or order them with events, exactly
+ * as for two kernels that share a buffer. */
 LPCNET_EXPORT int lpcnet_batch_synthesize_device(LPCNetBatch *b, const float *d_features, int feat_stride, short *d_pcm,
                                                  int n_frames, void *hip_stream);
 /* device-pointer synthesis on ONE shard of a sharded batch: pointers are on that shard's device and cover only its

@@ -110,6 +110,10 @@ def build_small_registry(verbose=False):
     -DLPCN_MAX_MODELS=4 -DLPCN_MAX_RESIDENT=2), so that tests reach the eviction paths that need > 256 distinct models in the product
     build (tests/test_gpu_wide.py; select with LPCNET_HIP_LIB).  Test artefact, git-ignored like every built library."""
     build(verbose=verbose)
+    objdir0 = os.path.join(HERE, "build")
+    needed = ("engine.o", "sample_s1.o", "sample_s2.o", "sample_s4.o", "sample_x2.o", "model_pack.o")
+    if not all(os.path.exists(os.path.join(objdir0, f)) for f in needed):      # (a prebuilt library whose hash matches skips the compile: its objects may be absent -- ADVICE r5)
+        build(force=True, verbose=verbose)
     lib = LIB.replace(".so", "_smallreg.so")
     h_src, h_dev = source_hashes()
     if baked_hashes(lib) == (h_src + "-smallreg", h_dev):

@@ -514,21 +514,24 @@ int lpcnet_hip_decoder_load_model(LPCNetDecState *st, const unsigned char *data,
  * lpcnet_hip_clear_error()) and a sticky per-model status (lpcnet_hip_model_status()).  Under the combining dispatcher every
  * caller of a failed pass gets its own zero-filled output and its own status.  The first few failures of a process are also
  * written to stderr (LPCNET_HIP_QUIET=1: never); LPCNET_HIP_ABORT_ON_ERROR=1 restores the old stop-with-a-message. */
+static __thread unsigned tl_fail_seq;                        /* failures recorded on this thread so far */
 static void entry_failed(const char *who, int code, registry_entry *r, const char *msg)
 {
+    tl_fail_seq++;
     char buf[sizeof(tl_err)];
     snprintf(buf, sizeof(buf), "%s: %s", who, msg ? msg : "");
     snprintf(tl_err, sizeof(tl_err), "%s", buf);
     if (!tl_status) tl_status = code;
-    if (r) {
-        int zero = 0;
-        __atomic_compare_exchange_n(&r->fail_code, &zero, code, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
-        __atomic_add_fetch(&r->fail_count, 1, __ATOMIC_SEQ_CST);
+    (void)r;                                                 /* (the per-model status is recorded by dispatch() while the slot is pinned) */
+    static int reported, env_read, env_fatal, env_quiet;     /* the two environment switches are read once (this is the per-frame path of a PLC that lost its device) */
+    if (!__atomic_load_n(&env_read, __ATOMIC_ACQUIRE)) {
+        const char *ab = getenv("LPCNET_HIP_ABORT_ON_ERROR");
+        env_fatal = ab && *ab == '1';
+        env_quiet = getenv("LPCNET_HIP_QUIET") != NULL;
+        __atomic_store_n(&env_read, 1, __ATOMIC_RELEASE);
     }
-    static int reported;
-    const char *ab = getenv("LPCNET_HIP_ABORT_ON_ERROR");
-    const int fatal = ab && *ab == '1';
-    if (fatal || (!getenv("LPCNET_HIP_QUIET") && __atomic_fetch_add(&reported, 1, __ATOMIC_SEQ_CST) < 8))
+    const int fatal = env_fatal;
+    if (fatal || (!env_quiet && __atomic_fetch_add(&reported, 1, __ATOMIC_SEQ_CST) < 8))
         fprintf(stderr, "%s%s\n", tl_err, fatal ? "" : " -- output zero-filled, see lpcnet_hip_status()");
     if (fatal) abort();
 }
@@ -666,7 +669,9 @@ static int tail_locked(registry_entry *r, LPCNetState *st, short *output, int N,
     lpcn_stream_state snew;
     int rc = push_state(r, &st->s);
     r->cache_valid = 0;
-    short *tmp = (short *)malloc(sizeof(short) * (size_t)N);      /* (the caller's buffer is written only when every piece has succeeded) */
+    short one[LPCN_FRAME_SIZE];                              /* (the caller's buffer is written only when every piece has succeeded; N <= 160 -- every caller in
+                                                              * the reference -- needs no heap) */
+    short *tmp = N <= LPCN_FRAME_SIZE ? one : (short *)malloc(sizeof(short) * (size_t)N);
     if (!tmp) { set_err("out of memory"); return LPCN_E_HIP; }
     for (int done = 0; !rc && done < N; done += LPCN_FRAME_SIZE) {
         const int n = N - done < LPCN_FRAME_SIZE ? N - done : LPCN_FRAME_SIZE;
@@ -679,10 +684,10 @@ static int tail_locked(registry_entry *r, LPCNetState *st, short *output, int N,
         if (!rc) memcpy(tmp + done, frame, sizeof(short) * (size_t)n);
     }
     if (!rc) rc = pull_state(r, &snew);
-    if (rc) { r->cache_valid = 0; free(tmp); return rc; }
+    if (rc) { r->cache_valid = 0; if (tmp != one) free(tmp); return rc; }
     st->s = snew;
     memcpy(output, tmp, sizeof(short) * (size_t)N);
-    free(tmp);
+    if (tmp != one) free(tmp);
     return 0;
 }
 
@@ -722,7 +727,10 @@ static int comb_run(registry_entry *r, comb_req **grp, int k)
     float *ga[COMB_MAX], *gb[COMB_MAX], *lp[COMB_MAX];
     for (int i = 0; i < k; i++) {
         sin[i] = &grp[i]->st->s; sout[i] = &grp[i]->st->s; ft[i] = grp[i]->feat; pc[i] = grp[i]->pcm;
-        ga[i] = grp[i]->ga; gb[i] = grp[i]->gb; lp[i] = grp[i]->lpc;
+        /* a plain lpcnet_synthesize never refreshes the frame products kept in the state -- not on the lone fast path, and therefore not here either
+         * (whether it did used to depend on whether another thread happened to call at the same time) */
+        const int takes = grp[i]->kind != LPCN_GROUP_FRAME_SAMPLES || grp[i]->want_products;
+        ga[i] = takes ? grp[i]->ga : NULL; gb[i] = takes ? grp[i]->gb : NULL; lp[i] = grp[i]->lpc;
     }
     r->cache_valid = 0;                                      /* (the one-stream batch's device copy is not what these states continue from) */
     return lpcn_batch_dev_run_group(r->gdev, k, q->kind, q->N, q->preload, sin, ft, pc, sout, ga, gb, lp);      /* (writes only after the pass has succeeded) */
@@ -796,7 +804,14 @@ static int dispatch(comb_req *me, registry_entry **rout)
         pthread_cond_broadcast(&r->q_cv);
     }
     pthread_mutex_unlock(&r->q_lock);
+    if (me->rc) {                                            /* the model's sticky status, recorded while the slot is still pinned (behind the unpin
+                                                              * the slot may already belong to another model) */
+        int zero = 0;
+        __atomic_compare_exchange_n(&r->fail_code, &zero, me->rc, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+        __atomic_add_fetch(&r->fail_count, 1, __ATOMIC_SEQ_CST);
+    }
     unpin_entry(r);
+    *rout = NULL;                                            /* (not to be touched behind the unpin) */
     if (me->rc) snprintf(tl_err, sizeof(tl_err), "%s", me->err);
     return me->rc;
 }
@@ -867,8 +882,12 @@ void lpcnet_synthesize_tail_impl(LPCNetState *st, short *output, int N, int prel
 void lpcnet_synthesize_impl(LPCNetState *st, const float *features, short *output, int N, int preload)
 {
     if (N > LPCN_FRAME_SIZE || N <= 0 || preload < 0 || preload > N) {      /* the reference's two steps, each with its own checks */
+        const LPCNetState keep = *st;                        /* atomic for the caller like the one-pass form: a failed second step puts the state back */
+        const unsigned seq0 = tl_fail_seq;
         run_frame_network(st, st->gru_a_condition, st->gru_b_condition, st->s.lpc, features);
-        if (N > 0) lpcnet_synthesize_tail_impl(st, output, N, preload);
+        if (N > 0 && tl_fail_seq == seq0) lpcnet_synthesize_tail_impl(st, output, N, preload);
+        else if (N > 0) memset(output + (preload > 0 && preload <= N ? preload : 0), 0, sizeof(short) * (size_t)(N - (preload > 0 && preload <= N ? preload : 0)));
+        if (tl_fail_seq != seq0) *st = keep;
         return;
     }
     comb_req me = {st, features, output, N, LPCN_GROUP_FRAME_SAMPLES, preload, 1, st->gru_a_condition, st->gru_b_condition, st->s.lpc, 0, 0, NULL, {0}};

@@ -70,16 +70,11 @@ struct lpcn_batch_dev {
     int *d_map = nullptr;              //   ... and its stream indices
     float *d_keep_a = nullptr, *d_keep_b = nullptr, *d_keep_lpc = nullptr;   //   ... and every stream's most recent frame products
     std::vector<char> keep_ok;         //   ... which exist only for streams whose last frame step went through the step call (mode 1)
-    float *d_hmir = nullptr;           // [stream slot][384] GRU-A state mirror read by GRU-B through the scalar cache (sample_kernel.hip.h: gb_scalar)
     unsigned char *d_packets = nullptr;
     size_t packets_cap = 0;
     short *d_pcm = nullptr;
     size_t feat_cap = 0, pcm_cap = 0;
     LpcnSampleArgs *d_args = nullptr;
-    // HIP-graph capture: a captured launch's argument block must outlive the call (the copy node reads its host source at every replay), so it
-    // is taken from a small pinned pool that lives as long as the batch instead of from the caller's stack
-    LpcnSampleArgs *h_cap_args = nullptr;
-    int cap_used = 0;
     float *d_dbg = nullptr;
     unsigned long long *d_prof = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -94,7 +89,10 @@ struct lpcn_batch_dev {
     float ms_sample = 0.f, ms_frame = 0.f;
 };
 
-#define LPCN_CAPTURE_SLOTS 32
+// HIP-graph capture: a captured copy node re-reads its HOST source at every replay, so the argument block of a captured launch cannot come from the
+// caller's stack -- it travels as the by-value parameter of a one-lane kernel instead, which the graph's kernel node owns (round 6, ADVICE r5: round 5's
+// pinned pool of 32 slots leaked a slot per captured launch and ended every capture after the 32nd)
+__global__ void lpcn_set_args_kernel(LpcnSampleArgs *dst, const LpcnSampleArgs a) { *dst = a; }
 static bool stream_is_capturing(hipStream_t st)
 {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -446,9 +444,7 @@ extern "C" int lpcn_batch_dev_create(lpcn_batch_dev **out, lpcn_engine *e, int n
     AL(b->d_lpc, sizeof(float) * (size_t)n * max_chunk * LPCN_LPC_ORDER);
     AL(b->d_cond, sizeof(float) * (size_t)n * (max_chunk + 4) * LPCN_COND * 2);
     AL(b->d_args, sizeof(LpcnSampleArgs));
-    if (hipHostMalloc((void **)&b->h_cap_args, sizeof(LpcnSampleArgs) * LPCN_CAPTURE_SLOTS, hipHostMallocDefault) != hipSuccess) b->h_cap_args = nullptr;      // (only capture needs it)
     AL(b->d_vq_mem, sizeof(float) * (size_t)n * LPCN_NB_BANDS);
-    AL(b->d_hmir, sizeof(float) * ((size_t)n + 4) * LPCN_N_A);       // workgroups x S slots: the last workgroup may be partly filled
 #undef AL
     for (auto &ev : b->ev) if (hipEventCreate(&ev) != hipSuccess) return fail(LPCN_E_HIP);
     if (hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming) != hipSuccess) return fail(LPCN_E_HIP);
@@ -464,10 +460,9 @@ extern "C" void lpcn_batch_dev_destroy(lpcn_batch_dev *b)
     DeviceGuard guard(b->e->device);
     (void)wait_all(b);
     if (b->h_pin) (void)hipHostFree(b->h_pin);
-    if (b->h_cap_args) (void)hipHostFree(b->h_cap_args);
     if (b->ev_last) (void)hipEventDestroy(b->ev_last);
     void *ptrs[] = {b->d_state, b->d_fc_base, b->d_cond_a, b->d_cond_b, b->d_lpc, b->d_cond, b->d_feat, b->d_pcm, b->d_args, b->d_dbg, b->d_prof,
-                    b->d_vq_mem, b->d_packets, b->d_hmir, b->d_state_tmp, b->d_map, b->d_keep_a, b->d_keep_b, b->d_keep_lpc};
+                    b->d_vq_mem, b->d_packets, b->d_state_tmp, b->d_map, b->d_keep_a, b->d_keep_b, b->d_keep_lpc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : b->ev) if (ev) (void)hipEventDestroy(ev);
     delete b;
@@ -571,6 +566,11 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
                          int preload, bool fc_from_frames)
 {
     if (b->S == 8 && !x2_available(b->e)) { b->S = 4; b->pack2 = false; }      // (the arithmetic flavour changed under a pinned value)
+    // (the two-group kernel addresses the launch's conditioning rows with 32-bit byte offsets: launches beyond 4 GB of them -- more than ~9 300 streams x
+    // 100 frames -- run on the four-stream kernel)
+    const int S_keep = b->S;
+    if (b->S == 8 && (unsigned long long)b->n * (unsigned long long)n_frames * LPCN_ROWS_A * 4ull >= (1ull << 32)) b->S = 4;
+    struct SRestore { lpcn_batch_dev *b; int s; ~SRestore() { b->S = s; } } s_restore{b, S_keep};
     LpcnSampleArgs a = b->S == 8 ? b->e->sargs_x2 : ((b->e->fast && b->e->has_fast_image) ? b->e->sargs_fast : b->e->sargs);
     a.n_streams = b->n; a.n_frames = n_frames; a.preload = preload; a.frame_len = b->frame_len;
     a.fc_advance = fc_from_frames ? 1 : 0;
@@ -579,16 +579,12 @@ static int launch_sample(lpcn_batch_dev *b, hipStream_t st, short *d_pcm, size_t
     a.pcm = d_pcm; a.pcm_stride = (long long)pcm_stride;
     a.state = b->d_state; a.dbg = b->d_dbg; a.prof = b->d_prof;
     a.fc_f16 = (b->e->fast && b->e->fc_f16) ? 1 : 0;
-    a.hmir = getenv("LPCNET_HIP_NO_SCALAR_GRUB") ? nullptr : b->d_hmir;      // (tools: the LDS + DPP form of GRU-B for comparison)
-    const LpcnSampleArgs *src = &a;
     if (stream_is_capturing(st)) {
-        if (!b->h_cap_args || b->cap_used >= LPCN_CAPTURE_SLOTS) {
-            snprintf(g_err, sizeof(g_err), "more than %d launches of one batch captured into HIP graphs", LPCN_CAPTURE_SLOTS); return LPCN_E_ARG;
-        }
-        b->h_cap_args[b->cap_used] = a;
-        src = &b->h_cap_args[b->cap_used++];
+        hipLaunchKernelGGL(lpcn_set_args_kernel, dim3(1), dim3(1), 0, st, b->d_args, a);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(b->d_args, &a, sizeof(a), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemcpyAsync(b->d_args, src, sizeof(a), hipMemcpyHostToDevice, st));
     const int i8 = b->e->is_int8 ? 1 : 0;
     const int fast = (b->e->fast ? 1 : 0) | (b->pack2 ? 2 : 0);
     const int nwv = cur_nw_variant(b->e);
@@ -865,7 +861,7 @@ extern "C" int lpcn_batch_dev_run_group(lpcn_batch_dev *b, int k, int kind, int 
         memcpy(st_out[i], pin + sz_st * i, sz_st);
         // live frames return the imposed samples unchanged; start-up frames are cleared entirely (src/lpcnet.c:239-243)
         if (samples) memcpy(pcm[i], pin + off_pcm + sizeof(short) * LPCN_FRAME_SIZE * i, sizeof(short) * (size_t)frame_len);
-        if (frames) {
+        if (frames && ga[i]) {                               // (ga[i] == NULL: this caller does not take the frame products back)
             memcpy(ga[i], pin + off_ga + sizeof(float) * LPCN_ROWS_A * i, sizeof(float) * LPCN_ROWS_A);
             memcpy(gb[i], pin + off_gb + sizeof(float) * LPCN_ROWS_B * i, sizeof(float) * LPCN_ROWS_B);
             if (kind == LPCN_GROUP_FRAMES) memcpy(lpc[i], pin + off_lpc + sizeof(float) * LPCN_LPC_ORDER * i, sizeof(float) * LPCN_LPC_ORDER);

@@ -32,15 +32,9 @@ struct LpcnFrameModel {
 namespace lpcn {
 
 constexpr int FT = 8;            // frames per tile (weight reuse factor)
-#ifndef LPCN_FRAME_UNROLL
 #define LPCN_FRAME_UNROLL 16     // trips of a weight loop unrolled together in the one-frame kernels: that many L2 loads of a lane in flight (the sums keep their order)
-#endif
-#ifndef LPCN_FRAME_UNROLL_F1
 #define LPCN_FRAME_UNROLL_F1 1   // ... in the chunk kernel (FT frames of one stream per tile: throughput-bound, the hint costs it 0.3 ms per 25-frame step)
-#endif
-#ifndef LPCN_FRAME_UNROLL_PJ8
 #define LPCN_FRAME_UNROLL_PJ8 1  // ... in the projection kernel with full tiles
-#endif
 #define LPCN_STR2(x) #x
 #define LPCN_STR(x) LPCN_STR2(x)
 #if LPCN_FRAME_UNROLL_F1 > 1
@@ -48,9 +42,7 @@ constexpr int FT = 8;            // frames per tile (weight reuse factor)
 #else
 #define LPCN_PRAGMA_F1           /* (the compiler's own choice, as before round 5) */
 #endif
-#ifndef LPCN_PROJ_SPLIT_MAX
 #define LPCN_PROJ_SPLIT_MAX 2048 // (stream, frame) items up to which the projection's ten row blocks are separate workgroups
-#endif
 constexpr int FIN = LPCN_FRAME_IN, CN = LPCN_COND;
 
 // ---------------------------------------------------------------------------------------------

@@ -51,16 +51,10 @@ extern "C" {
  * candidate head (LPCN_DEAL_HMASK_I8: bit w = wave w may), LPCN_DEAL_EH_I8 items long.  Measured (1024 streams, bit-exact):
  * waves 0,1 / 2,3 / 1,3 / 1,2 -> 157.6 / 163.3 / 160.7 / 160.1 M samples/s; head 10 / 14 / 16 / 18 / 20 / 22 / 24 items with 2,3 ->
  * 157.3 / 163.3 / 166.1 / 167.9 / 164.6 / 169.0 / 168.3 M (gpurun_out of round 5, two runs each within 0.2 M). */
-#ifndef LPCN_I8_GBWA
 #define LPCN_I8_GBWA 2
 #define LPCN_I8_GBWB 3
-#endif
-#ifndef LPCN_DEAL_HMASK_I8
 #define LPCN_DEAL_HMASK_I8 (0xFFu & ~((1u << LPCN_I8_GBWA) | (1u << LPCN_I8_GBWB)))
-#endif
-#ifndef LPCN_DEAL_EH_I8
 #define LPCN_DEAL_EH_I8 22
-#endif
 /* the two-group float kernel (sample_kernel_x2.hip.h): GRU-B's chains -- one stream each -- run on waves 0 .. LPCN_X2_CHAIN_WAVES - 1; waves LPCN_X2_P0_FIRST .. 7
  * carry one candidate slot each (its head runs in the chains' shadow) and run the start-value pass, wave LPCN_X2_P0_FIRST also leads the streams; at most
  * LPCN_X2_NW_MAX register-resident items per lane */

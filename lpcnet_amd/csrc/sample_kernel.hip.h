@@ -24,9 +24,8 @@
 //     exchanged with wave shuffles (no barrier).  Float blobs with a dense GRU-B input matrix: its state operand -- the same
 //     384 values for every row -- is a BROADCAST LDS read of the block the gate stage has just written, and the whole 96-block
 //     loop is one hand-scheduled assembly block (grub_lds_loop_s{1,2,4}.inc, tools/gen_grub_asm.py --lds S; round 4).
-//     (LPCN_GRUB_LDS=0 builds keep round 3's form: the gate stage mirrors the new state into an L2-resident buffer and the
-//     GRU-B wave pulls it through the scalar cache into SGPR-pair operands of v_pk_mul_f32, grub_scalar_loop.inc.)  int8 blobs
-//     and block-sparse matrices use the LDS + DPP / dot4 forms below.
+//     int8 blobs and block-sparse matrices use the LDS + DPP / dot4 forms below.  (Round 3's form -- the state mirrored into an L2-resident buffer
+//     and pulled through the scalar cache into SGPR-pair operands -- and the other measured alternatives are in the history: EXPERIMENTS.md.)
 //   * dual-FC tree: all 255 nodes x 2 channels are evaluated in parallel (lane = node,channel;
 //     18 weight VGPRs), a ballot per wave yields the 255 decision bits.  Speculative evaluation
 //     is exact: every node's logit is a pure function of the GRU-B state.
@@ -35,16 +34,13 @@
 //     Wave 1 draws the KISS99 thresholds of the next sample.
 //
 // Schedule of one sample (4 workgroup barriers B1..B4):
-//   P1 GRU-A rows | B1 | P2 gates (+ state mirror stores) | B2 | P3 GRU-B (waves < S)  ||  the HEAD of the next sample's
+//   P1 GRU-A rows | B1 | P2 gates | B2 | P3 GRU-B (waves < S)  ||  the HEAD of the next sample's
 //   candidate chains on waves 4..7 | B3 | P4 tree | B4 | leader publishes the next sample's mu-law indices through an LDS
 //   flag -- no barrier: the other waves are already in P1, running what needs neither the indices nor the gathered
 //   embedding rows (the TAIL of their candidate chains), then poll the flag and gather.
 //   A candidate row's sum is sequential, but it need not be formed in one go: model_pack.c stores the first `head` blocks of
 //   every row of a wave's candidate slot end-aligned in the item array; waves 4..7 run them one sample ahead in GRU-B's
 //   shadow, park the partial sums in LDS, and the slot continues from there in P1.
-//   The mirror stores of P2 are not waited for at B2: every wave bumps an LDS arrival counter once its stores are
-//   acknowledged by L2, and a GRU-B wave starts its scalar loads when all eight have arrived (it forms the recurrent part
-//   meanwhile).
 //
 // Round 5:
 //   * int8 blobs, <= 2 streams per workgroup (two workgroups per CU): GRU-B's chain waves are 2 and 3, not 0 and 1 -- wave 0 also leads the
@@ -52,8 +48,6 @@
 //     candidate heads of up to 22 items (lpcnet_engine.h: LPCN_I8_GBWA / _GBWB, LPCN_DEAL_HMASK_I8, LPCN_DEAL_EH_I8).
 //   * float blobs with more than 32 items per lane keep 28 in VGPRs and STREAM the rest from L2 every sample (see NR / fetch_w): no variant
 //     has a scratch access inside the sample loop any more, and 48 items per lane (1.83 x the benchmark model's blocks) load.
-//   * a ring of PRODUCTS for GRU-B's last ten blocks at four streams per workgroup (LPCN_GRUB_RING) was built, is bit-exact and is slower;
-//     it stays as a compile-time switch with its phase tables (profiles/r05_phase_clocks_grub_ring.txt).
 //
 // FAST (lpcnet_batch_set_fast) frees the order of a row's sum, and the kernel then uses the matrix pipe: a GRU-A item is
 // four v_mfma_f32_4x4x1 (4 rows' weights x 4 streams' state values per quad), and -- float blobs, dense GRU-B -- the GRU-B
@@ -64,7 +58,7 @@
 //     every later LDS wait to lgkmcnt(0) until both counters have been drained: the state prefetch of the item chains no
 //     longer overlapped anything.  All trace stores go through address-space-1 pointers.
 //   * a member of the argument block read inside the loop is a scalar load, and a scalar load in flight forces lgkmcnt(0)
-//     as well (SMEM returns out of order); see HOIST below.
+//     as well (SMEM returns out of order); see the argument-block members fetched once below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -102,7 +96,6 @@ struct LpcnSampleArgs {
     short *pcm;                                     // [stream] x pcm_stride samples, frame f at +f*160
     long long pcm_stride;
     lpcn_stream_state *state;                       // [stream]
-    float *hmir;                                    // [n_streams + 4][384] L2-resident mirror of the GRU-A state for GRU-B's scalar loads (or NULL)
     float *dbg;                                     // optional per-sample trace (tests)
     unsigned long long *prof;                       // optional: [8] shader-clock totals per phase, workgroup 0 wave 0
     const uint32_t *fc_wh;                          // FAST sub-option: dual-FC weights as fp16 pairs [256][2][8] (BASELINE config 4: "fp16 dual-FC")
@@ -112,9 +105,6 @@ struct LpcnSampleArgs {
 
 #ifndef LPCN_ENABLE_PROF
 #define LPCN_ENABLE_PROF 0
-#endif
-#ifndef LPCN_PARITY_MFMA
-#define LPCN_PARITY_MFMA 2      // PARITY float items: 1 = matrix pipe as exact multiplier + 16 adds, 2 = + packed adds over stream pairs (S = 4)
 #endif
 #define LPCN_DBG_STRIDE 1600    // floats per (sample) trace record: hA 384, hB 16, exc,sig,pred,pcm,pred, leader clocks barrier->publish, the tree's own decision; [448..1600) GRU-A pre-activations
 
@@ -137,19 +127,8 @@ template <typename T> __device__ __forceinline__ LPCN_GLOBAL T *as_global_rw(T *
 #define LPCN_REMAT_V(x) asm volatile("" : "+v"(x))
 #define LPCN_REMAT_S(x) asm volatile("" : "+s"(x))
 
-#ifndef LPCN_ROW_LDS
-#define LPCN_ROW_LDS 0          // 1: the lane's row numbers live in LDS instead of three VGPRs (measured in round 4: 122.7 vs 124.8 M -- slower; the table then costs 6 KB)
-#endif
 // ---- LDS carve-up (bytes), all offsets multiples of 16 ---------------------------------------
-#ifndef LPCN_PROD_BLOCKS
-#define LPCN_PROD_BLOCKS 48
-#endif
-#ifndef LPCN_GRUB_RING
-#define LPCN_GRUB_RING 0        // 1 / 2: four float streams per workgroup -- waves 4..7 form the products of GRU-B's last 10 blocks of their partner stream before / after their
-                                // candidate heads (see Lds<S>::RING_BLOCKS).  MEASURED AND NOT KEPT (round 5): bit-exact, 125.6 (before) / 121.5 (after) vs 126.8 M
-                                // samples/s -- the ten blocks cost the producer 1.9 k clk (not 0.5 k) and the chain wave's GRU-B gets 0.2 k LONGER: the phase is bound by what the four
-                                // chain waves + four head waves already ask of the LDS pipe, and products through LDS are one more KB written and read per block (EXPERIMENTS.md)
-#endif
+#define LPCN_PROD_BLOCKS 48      // single stream per workgroup: blocks of GRU-B whose products the helper waves form (the two assembly loops are generated for this split)
 template <int S> struct Lds {
     static constexpr int HA_STRIDE = 16 * S;                       // bytes per 4-neuron block
     static constexpr int hA     = 0;
@@ -178,18 +157,13 @@ template <int S> struct Lds {
     static constexpr int bstart = bbias + 2 * RB * 4;               // [8] i32
     static constexpr int bblk   = bstart + 32;                      // [<=608] u8, groups padded to x4
     static constexpr int boff   = bblk + 608;                       // [<=608] u16 LDS offsets of the GRU-B input blocks
-    static constexpr int rowtab = boff + 1216;                      // [3][512] i32: the rows a lane owns (-1: none) -- an LDS read where a VGPR would be spilled to scratch
-    static constexpr int bw     = rowtab + (LPCN_ROW_LDS ? 3 * LPCN_WG_THREADS * 4 : 0); // [nb_b padded][8][4] f32   (round 5: the row table is only carved out when it is used -- it was 6 KB of dead LDS in every variant)
+    static constexpr int bw     = boff + 1216;                      // [nb_b padded][8][4] f32
     static constexpr int hBh(int nb_b, bool i8) { return bw + (nb_b + (i8 ? 28 : 8)) * (i8 ? 32 : 128); }     // [S][16] f16: GRU-B state as halves (FAST fp16 dual FC), behind everything else
     // single-stream PARITY float: idle waves hand GRU-B's chain wave the PRODUCTS of the last PROD_BLOCKS blocks through LDS
     // ([block][48 rows] float4, 768 B per block) -- the chain then costs one read + four adds per block instead of two reads, two
     // packed multiplies and four adds.  Only S = 1 has the room (50 KB free of the 160 KB).
     static constexpr int PROD_BLOCKS = LPCN_PROD_BLOCKS, PROD_FIRST = 96 - PROD_BLOCKS;      // (the two assembly loops are generated for this split)
-    // four streams per workgroup (round 5): a RING of products for GRU-B's last RING_BLOCKS blocks of every stream, formed by waves 4..7 before their
-    // candidate heads.  10 blocks x 4 streams x 768 B = 30.7 KB live in cells that are dead while GRU-B runs -- the update / reset pre-activations
-    // (RING_SEG0 = 4 blocks per stream), the candidate inputs (RING_SEG1 = 2) -- and in the 12 KB that were free (RING_SEG2 = 4: `prod`).
-    static constexpr int RING_BLOCKS = 10, RING_FIRST = 96 - RING_BLOCKS, RING_SEG0 = 4, RING_SEG1 = 2, RING_SEG2 = 4;
-    static constexpr int prod_sz = S == 1 ? (PROD_BLOCKS + 7) * RB * 16 : (S == 4 && LPCN_GRUB_RING ? S * RING_SEG2 * RB * 16 : 0);      // (S = 1, + 7 blocks: the chain wave's ring of eight reads ahead past the last block on its last trip)
+    static constexpr int prod_sz = S == 1 ? (PROD_BLOCKS + 7) * RB * 16 : 0;      // (S = 1, + 7 blocks: the chain wave's ring of eight reads ahead past the last block on its last trip)
     static constexpr int prod(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }
     static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? 0 : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
@@ -222,20 +196,14 @@ template <int SEL> __device__ __forceinline__ float fmac_quad(float acc, const f
 //   x_q = (signed char)(int)floor(.5 + 127*x)   (float product, double sum)
 //   out = out*(128*127);  out += (w0*x0 + w1*x1 + w2*x2 + w3*x3) per block (exact integer);  out *= 1/128/127
 constexpr float QS = 128.f * 127.f, QS1 = 1.f / 128.f / 127.f;
-#ifndef LPCN_QUANT_RPI
-#define LPCN_QUANT_RPI 1        // 1: floor(.5 + t) as ONE instruction, v_cvt_rpi_i32_f32 (round to nearest, ties toward +infinity), instead of four in double (round 5: 157.5 vs 156.8 M int8)
-#endif
 __device__ __forceinline__ int quant_s8(float x)
 {
     const float t = 127.f * x;
-#if LPCN_QUANT_RPI
-    // == (int)floor(.5 + (double)t) for every finite t (lpcnet_hip_quant_sweep_device: all 2^32 bit patterns on the device)
+    // floor(.5 + t) as ONE instruction, v_cvt_rpi_i32_f32 (round to nearest, ties toward +infinity): == (int)floor(.5 + (double)t) for every finite t
+    // (lpcnet_hip_quant_sweep_device: all 2^32 bit patterns on the device)
     int q;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(t));
     return q & 0xFF;
-#else
-    return (int)floor(.5 + (double)t) & 0xFF;
-#endif
 }
 // Integer dot products converted to float.  v_dot4_i32_i8 with a literal-zero accumulator saves the
 // v_mov the compiler's v_dot4c selection needs, but the hazard recogniser cannot see inside inline
@@ -255,17 +223,6 @@ __device__ __forceinline__ void dot4_cvt_x4(float (&f)[4], int w0, int w1, int w
         "v_cvt_f32_i32 %3, %7"
         : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
         : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
-}
-__device__ __forceinline__ void dot4_cvt_x2(float (&f)[2], int w0, int w1, int x0, int x1)
-{
-    int t0, t1;
-    asm("v_dot4_i32_i8 %2, %4, %6, 0\n\t"
-        "v_dot4_i32_i8 %3, %5, %7, 0\n\t"
-        "s_nop 1\n\t"
-        "v_cvt_f32_i32 %0, %2\n\t"
-        "v_cvt_f32_i32 %1, %3"
-        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(t0), "=&v"(t1)
-        : "v"(w0), "v"(w1), "v"(x0), "v"(x1));
 }
 __device__ __forceinline__ float dot4_cvt(int w, int x)
 {
@@ -294,14 +251,6 @@ template <int J> __device__ __forceinline__ float lpc_chain(float r, float prod)
     else return r;
 }
 
-// ---- GRU-B input mat-vec with the state operand in SGPRs (PARITY, float blobs, dense input matrix) -----------------------
-// Every row of GRU-B multiplies the SAME 384 state values: a wave-uniform operand.  Instead of LDS reads + DPP quad
-// broadcasts (a DPP-operand instruction costs ~9 clk of issue, an LDS read ~30), the gate stage mirrors the new state into
-// an L2-resident buffer and the stream's GRU-B wave pulls it through the scalar cache: s_load_dwordx16 = 4 blocks, used as
-// SGPR-pair operands of v_pk_mul_f32 (two separately rounded products per instruction; tools/ubench/grub2.hip: 48 clk per
-// block against 77-83).  SMEM returns out of order, so every wait is lgkmcnt(0), and a scalar load must never be in flight
-// across an inline-asm boundary (the register allocator may spill or copy a tuple it believes defined): loads, waits and
-// consumers are ONE assembly block with its own registers, generated by tools/gen_grub_asm.py (grub_scalar_loop.inc).
 // PACK2 variants: the register allocation leaves room for 4 waves per SIMD (128 VGPRs per lane), i.e. TWO workgroups per
 // CU, which fill each other's barrier / latency bubbles (measured: a second resident workgroup slows the first by only
 // ~15 %).  Only the int8 kernels with <= 32 items per lane and S <= 2 get there without a scratch access inside the
@@ -351,10 +300,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 {
     using L = Lds<S>;
     using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
-#ifndef LPCN_I8_MFMA
-#define LPCN_I8_MFMA 1          // PARITY, int8 blobs, S >= 2: an item's block products of all streams from one v_mfma_i32_4x4x4i8 (exact integers, like v_dot4)
-#endif
-    constexpr bool I8M = I8 && !FAST && S >= 2 && LPCN_I8_MFMA;
+    constexpr bool I8M = I8 && !FAST && S >= 2;             // PARITY, int8 blobs, S >= 2: an item's block products of all streams from one v_mfma_i32_4x4x4i8 (exact integers, like v_dot4)
     using HT = typename std::conditional<I8, typename std::conditional<I8M, int, typename XVec<S>::type>::type, float4>::type;   // one fetched state block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const sm_pre = (float *)(smem + L::pre);
@@ -394,32 +340,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const auto *const emb_exc = as_global(Ap->emb_exc);
 
     // ------------------------------------------------------------------ resident weights ----
-    // Float blobs denser than 32 items per lane: the first LPCN_NR_F32 items of a lane stay in VGPRs, the others are STREAMED -- re-fetched from
+    // Float blobs denser than 32 items per lane: the first 28 items of a lane stay in VGPRs, the others are STREAMED -- re-fetched from
     // the L2-resident item array every sample, WSD - 1 items ahead of their use, into a ring of WSD registers quads.  (Round 4 kept all 36 / 40
     // items resident: the allocator then spilled into the sample loop -- 94 scratch accesses per sample at 40 items, 91 M samples/s for a model
     // with 1.53 x the benchmark model's blocks.  A spilled weight costs the same 1 KB per wave and sample as a streamed one, but its reload sits
     // right in front of its use.)  Only the waves that own more than NR items ever execute a streamed one.
-#ifndef LPCN_NR_F32
-#define LPCN_NR_F32 28
-#endif
-#ifndef LPCN_WS_DEPTH
-#define LPCN_WS_DEPTH 4
-#endif
-#ifndef LPCN_NR36
-#define LPCN_NR36 LPCN_NR_F32
-#endif
-    constexpr int NR = (!I8 && NW > (LPCN_GRUB_RING ? 30 : 32)) ? (NW <= 36 ? LPCN_NR36 : LPCN_NR_F32) : NW;      // resident items (a build with GRU-B's product ring streams at 32 items already)
-    constexpr int WSD = LPCN_WS_DEPTH;
+    constexpr int NR = (!I8 && NW > 32) ? 28 : NW;          // resident items (ring depth 4 / 6 and 24 / 28 / 32 resident items measured within 1 %)
+    constexpr int WSD = 4;
     WT w[NR];
     WT ws[NR < NW ? WSD : 1] = {};
     uint32_t offp[(NW + 1) / 2];
     int row_reg[3];
-#if LPCN_ROW_LDS
-    const int *const sm_row = (const int *)(smem + L::rowtab) + tid0;
-#define LPCN_ROW(k) (sm_row[(k) * LPCN_WG_THREADS])
-#else
 #define LPCN_ROW(k) (row_reg[k])
-#endif
     {
         const int lane = tid0 & 63, wave = tid0 >> 6;
         const size_t base = (size_t)wave * NW * 64 + lane;
@@ -450,9 +382,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             row_reg[k] = ar[(wave * 3 + k) * 64 + lane];
-#if LPCN_ROW_LDS
-            ((int *)(smem + L::rowtab))[k * LPCN_WG_THREADS + tid0] = row_reg[k];
-#endif
         }
     }
     int b1 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 1]);
@@ -460,43 +389,27 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     int b3 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_bound)[(tid0 >> 6) * 4 + 3]);   // this wave's item count
     const bool allh0 = __builtin_amdgcn_readfirstlane(as_global(Ap->a_allh)[(tid0 >> 6) * 3]) != 0;
     const bool b_dense = Ap->b_dense != 0;
-    // PARITY, float blob, dense GRU-B input matrix: GRU-B takes the GRU-A state through scalar loads (see grub_scalar_loop.inc)
-#ifndef LPCN_GRUB_LDS
-#define LPCN_GRUB_LDS 1         // 1: PARITY float GRU-B reads the state from LDS as a broadcast (grub_lds_loop_s*.inc) instead of the L2 mirror + SGPRs
-#endif
-    const bool gb_lds = LPCN_GRUB_LDS && !I8 && !FAST && b_dense;
-    const bool gb_scalar = !LPCN_GRUB_LDS && !I8 && !FAST && b_dense && Ap->hmir != nullptr;
-#ifndef LPCN_GRUB_PROD
-#define LPCN_GRUB_PROD 1        // 1: single stream per workgroup -- waves 1..3 form the products of GRU-B's last 64 blocks for the chain wave
-#endif
-    const bool gb_prod = LPCN_GRUB_PROD && S == 1 && gb_lds;
-    const bool gb_ring = LPCN_GRUB_RING && S == 4 && gb_lds;
-    // Argument-block members the sample loop needs on its critical path, fetched ONCE and made opaque: left to itself the
-    // compiler re-reads them with a scalar load at every use (cheaper than keeping an SGPR, it thinks), and a scalar load in
-    // flight forces every LDS wait behind it to lgkmcnt(0) -- right behind a barrier that is a stall for every wave (int8:
-    // 148 -> 154.5 M samples/s).  A spilled SGPR comes back with one v_readlane.  The PARITY float kernels are the
-    // exception: they have no SGPR to spare (the scalar-state GRU-B owns 36), and the ten more spilled ones cost what the
-    // loads did (109.5 M without, 108.7 M with) -- they keep the plain member reads.
-#ifndef LPCN_HOIST_ALL
-#define LPCN_HOIST_ALL 1
-#endif
-    constexpr bool HOIST = I8 || FAST || LPCN_HOIST_ALL;
+    // PARITY, float blob, dense GRU-B input matrix: GRU-B reads the GRU-A state from LDS as a broadcast (grub_lds_loop_s*.inc)
+    const bool gb_lds = !I8 && !FAST && b_dense;
+    const bool gb_prod = S == 1 && gb_lds;                   // single stream per workgroup: waves 1..3 form the products of GRU-B's last PROD_BLOCKS blocks for the chain wave
+    // Argument-block members the sample loop needs on its critical path are fetched ONCE and made opaque: left to itself the compiler re-reads them
+    // with a scalar load at every use, and a scalar load in flight forces every LDS wait behind it to lgkmcnt(0) -- right behind a barrier that is a
+    // stall for every wave (int8: 148 -> 154.5 M samples/s; float: 124.8 -> 125.4 M once GRU-B's scalar-state form had freed its 36 SGPRs).
     int tracing_s = 0;                                       // tests only: workgroup 0 writes the per-sample trace
-    if constexpr (HOIST) { tracing_s = __builtin_amdgcn_readfirstlane((Ap->dbg != nullptr && blockIdx.x == 0) ? 1 : 0); LPCN_REMAT_S(tracing_s); }
-// (the non-hoisted forms spell the tests exactly as before: the PARITY float kernels' register allocation is that fragile)
-#define tracing (HOIST ? tracing_s != 0 : (Ap->dbg && blockIdx.x == 0))
-#define tracing_any (HOIST ? tracing_s != 0 : Ap->dbg != nullptr)
-#define tracing_lane0(extra) (HOIST ? (tracing_s != 0 && tid == 0 && (extra)) : (Ap->dbg && tid == 0 && blockIdx.x == 0 && (extra)))
+    { tracing_s = __builtin_amdgcn_readfirstlane((Ap->dbg != nullptr && blockIdx.x == 0) ? 1 : 0); LPCN_REMAT_S(tracing_s); }
+#define tracing (tracing_s != 0)
+#define tracing_any (tracing_s != 0)
+#define tracing_lane0(extra) (tracing_s != 0 && tid == 0 && (extra))
     const LPCN_GLOBAL float *fc_w_s = nullptr, *fc_b_s = nullptr, *fc_f_s = nullptr;
-    if constexpr (HOIST) {
+    {
         fc_w_s = as_global(Ap->fc_w); fc_b_s = as_global(Ap->fc_b); fc_f_s = as_global(Ap->fc_f);
         asm volatile("" : "+s"(fc_w_s), "+s"(fc_b_s), "+s"(fc_f_s));
     }
     const LPCN_GLOBAL char *aw_s = (const LPCN_GLOBAL char *)as_global(Ap->a_w);       // item array, for the streamed items (NR < NW)
     if constexpr (NR < NW) asm volatile("" : "+s"(aw_s));
-#define fc_w_g (HOIST ? fc_w_s : as_global(Ap->fc_w))
-#define fc_b_g (HOIST ? fc_b_s : as_global(Ap->fc_b))
-#define fc_f_g (HOIST ? fc_f_s : as_global(Ap->fc_f))
+#define fc_w_g fc_w_s
+#define fc_b_g fc_b_s
+#define fc_f_g fc_f_s
     // bit k: this wave owns rows in slot k (wave-uniform)
     const int has_slot = __builtin_amdgcn_readfirstlane((__ballot(row_reg[0] >= 0) != 0ull ? 1 : 0) | (__ballot(row_reg[1] >= 0) != 0ull ? 2 : 0) |
                                                         (__ballot(row_reg[2] >= 0) != 0ull ? 4 : 0));
@@ -506,7 +419,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // the partial sums (the raw accumulators: scaled by 128*127 for int8 blobs, an int32 pattern in FAST) in the rows' sm_pre
     // cells; the slot then starts from those in the next sample.
     const int hl = __builtin_amdgcn_readfirstlane(as_global(Ap->a_head)[tid0 >> 6]);
-    const bool early_wave = hl > 0;                          // wave-uniform (model_pack.c deals heads to waves 4..7 only: never a GRU-B wave)
+    const bool early_wave = hl > 0;                          // wave-uniform (model_pack.c: float blobs -- waves 4..7 only, never a GRU-B wave; int8 blobs at <= 2 streams -- every wave except GRU-B's chain waves 2, 3: LPCN_DEAL_HMASK_I8)
 
     // ------------------------------------------------------------------ LDS residents -------
     {
@@ -664,23 +577,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (v != seq) __builtin_amdgcn_s_sleep(1);
         } while (v != seq);
     };
-    // State mirror hand-off (gb_scalar): a wave's mirror stores are in L2 once its s_waitcnt vmcnt(0) returns; it then bumps an
-    // arrival counter in LDS, and a GRU-B wave starts its scalar loads when all eight waves of this sample have arrived.  The
-    // store round trip (~500 clk) is off the barrier path: GRU-B waves form the recurrent part first, the others go on.
+    // Arrival counter in LDS for hand-offs without a workgroup barrier (FAST float GRU-B on the matrix pipe: every wave bumps it behind its LDS stores -- a wave's
+    // LDS operations complete in order -- and only the gate waves wait for all eight)
     int gbseq = 0;                                           // samples handed off so far (identical in every wave)
     const uint32_t arrive_addr = flag_addr + 4;
-    auto mirror_arrive = [&]() {
-        // one lane bumps the counter; EXEC is narrowed INSIDE the statement: a compiler-visible `if (lane == 0)` next to the
-        // GRU-B assembly block (40 clobbered VGPRs) made hipcc 7.2 place its vacate copies inside the masked region
-        int one = 1;
-        unsigned long long ex;
-        asm volatile("s_waitcnt vmcnt(0)\n\t"
-                     "s_mov_b64 %0, exec\n\t"
-                     "s_mov_b64 exec, 1\n\t"
-                     "ds_add_u32 %1, %2\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(ex) : "v"(arrive_addr), "v"(one) : "memory");
-    };
     auto lds_arrive = [&]() {                                 // the same counter for hand-offs through LDS: no store round trip to wait for
         int one = 1;
         unsigned long long ex;
@@ -714,7 +614,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     };
     auto prod_wait = [&]() {
         int v;
-        const int want = prseq * (S == 4 ? 4 : 3);          // (producers: waves 1..3 of a single-stream workgroup, waves 4..7 of a four-stream one)
+        const int want = prseq * 3;                          // (producers: waves 1..3 of a single-stream workgroup)
         do {
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(prod_cnt_addr) : "memory");
             v = __builtin_amdgcn_readfirstlane(v);
@@ -820,10 +720,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_PROF(5);
             float acc[S] = {};                               // (initialised for the same reason as ge)
             // state blocks are fetched PF items ahead of their use
-#ifndef LPCN_PF
-#define LPCN_PF 2
-#endif
-            constexpr int PF = LPCN_PF;
+            constexpr int PF = 2;                            // (1 / 2 / 3 items ahead: 124.4 / 124.8 / 125.1 M in round 4 -- noise)
             HT hq[PF + 1] = {};
             auto fetch_h = [&](const int j) {
                 uint32_t pk = offp[j >> 1];
@@ -844,12 +741,12 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 if constexpr (NR < NW) return j < NR ? w[j < NR ? j : 0] : ws[(j >= NR ? j - NR : 0) % WSD];
                 else return w[j];
             };
-            // (LPCN_PARITY_MFMA == 2) the matrix pipe's addend: four registers of -0.0, re-materialised where an item chain starts so
+            // the matrix pipe's addend (PARITY float items, S >= 2): four registers of -0.0, re-materialised where an item chain starts so
             // that they are not live across the other phases
             typedef float negz_t __attribute__((ext_vector_type(4)));
             negz_t negz = {-0.f, -0.f, -0.f, -0.f};
             auto load_negz = [&]() { negz = (negz_t){-0.f, -0.f, -0.f, -0.f}; asm volatile("" : "+v"(negz)); };
-            if constexpr (!I8 && !FAST && S >= 2 && LPCN_PARITY_MFMA == 2) load_negz();
+            if constexpr (!I8 && !FAST && S >= 2) load_negz();
             // one item = (this lane's row) x (one 4-wide input block) for all S streams
             auto mac = [&](const int j) {
                 // one item = (this lane's row) x (one 4-wide input block) for all S streams; per output
@@ -879,19 +776,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                 } else if constexpr (I8) {
                     // one dot4 = the row's block product for one stream, exact in int32 (src/vec.h:329-334)
-                    const HT xv = hq[j % (PF + 1)];
-                    if constexpr (S == 4) {
-                        float d[4];
-                        dot4_cvt_x4(d, w[j], w[j], w[j], w[j], xv[0], xv[1], xv[2], xv[3]);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) acc[s] = acc[s] + d[s];
-                    } else if constexpr (S == 2) {
-                        float d[2];
-                        dot4_cvt_x2(d, w[j], w[j], xv[0], xv[1]);
-                        acc[0] = acc[0] + d[0]; acc[1] = acc[1] + d[1];
-                    } else {
-                        acc[0] = acc[0] + dot4_cvt(w[j], xv);
-                    }
+                    static_assert(S == 1, "int8 PARITY items of two or four streams run on the matrix pipe (I8M)");
+                    acc[0] = acc[0] + dot4_cvt(w[j], hq[j % (PF + 1)]);
                 } else {
                 const float4 hv = hq[j % (PF + 1)];
                 const float hk[4] = {hv.x, hv.y, hv.z, hv.w};
@@ -912,7 +798,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     acc[0] = av[0]; acc[1] = av[1];
                     if constexpr (S == 4) { acc[2] = av[2]; acc[3] = av[3]; }
                 }
-                if constexpr (!FAST && S >= 2 && LPCN_PARITY_MFMA == 2) {
+                if constexpr (!FAST && S >= 2) {
                     // the products of a column for all streams of the quad from ONE matrix-pipe instruction (C = -0.0: bit for bit the
                     // separately rounded product), the sums as v_pk_add_f32 over stream pairs -- each half of a packed add is
                     // rounded on its own, so the order of every row's sum is still the reference's: 4 MFMA + 8 packed adds per
@@ -934,35 +820,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                     acc[0] = a01[0]; acc[1] = a01[1];
                     if constexpr (S == 4) { acc[2] = a23[0]; acc[3] = a23[1]; }
-                } else if constexpr (!FAST && S >= 2 && LPCN_PARITY_MFMA) {
-                    // PARITY: the same instruction as a MULTIPLIER -- with C = -0.0 the fused result is the separately rounded
-                    // product bit for bit (x + (-0) = x, also for zeros), one instruction instead of the four DPP multiplies of a
-                    // column; the sums stay ordinary adds in the reference's order.
-                    typedef float f4 __attribute__((ext_vector_type(4)));
-                    f4 nz;
-                    nz[0] = nz[1] = nz[2] = nz[3] = -0.f;
-                    asm volatile("" : "+v"(nz));             // (one 4-register tuple, re-materialised per item)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f4 pv = __builtin_amdgcn_mfma_f32_4x4x1f32(hk[c], wk[c], nz, 0, 0, 0);
-                        acc[0] = acc[0] + pv[0]; acc[1] = acc[1] + pv[1];
-                        if constexpr (S == 4) { acc[2] = acc[2] + pv[2]; acc[3] = acc[3] + pv[3]; }
-                    }
                 } else
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if constexpr (FAST) {
                         if constexpr (S == 1) acc[0] = __builtin_fmaf(wk[c], hk[c], acc[0]);
                         // (S >= 2: all four columns at once below, on the matrix pipe)
-                    } else if constexpr (S == 1) {
-                        acc[0] = acc[0] + wk[c] * hk[c];
-                    } else if constexpr (S == 2) {
-                        const float t0 = wk[c] * quad_bcast<0>(hk[c]), t1 = wk[c] * quad_bcast<1>(hk[c]);
-                        acc[0] = acc[0] + t0; acc[1] = acc[1] + t1;
                     } else {
-                        const float t0 = wk[c] * quad_bcast<0>(hk[c]), t1 = wk[c] * quad_bcast<1>(hk[c]);
-                        const float t2 = wk[c] * quad_bcast<2>(hk[c]), t3 = wk[c] * quad_bcast<3>(hk[c]);
-                        acc[0] = acc[0] + t0; acc[1] = acc[1] + t1; acc[2] = acc[2] + t2; acc[3] = acc[3] + t3;
+                        static_assert(FAST || S == 1, "PARITY float items of two or four streams run on the matrix pipe");
+                        acc[0] = acc[0] + wk[c] * hk[c];
                     }
                 }
                 }
@@ -1038,7 +904,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             LPCN_REMAT_S(jstar);
             // The early head of slot 0 (see `hl`): one compile-time chain over the last LPCN_EARLY_MAX items, entered at NW - hl.
             auto run_head = [&]() __attribute__((always_inline)) {
-                if constexpr (!I8 && !FAST && S >= 2 && LPCN_PARITY_MFMA == 2) load_negz();
+                if constexpr (!I8 && !FAST && S >= 2) load_negz();
                 {
                     int r = LPCN_ROW(0);
                     LPCN_REMAT_V(r);
@@ -1245,9 +1111,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                             smem[L::xqT + (s * 96 + (n >> 2)) * 4 + (n & 3)] = qv;
                         } else {
                             *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv;
-                            if constexpr (!FAST) {
-                                if (gb_scalar) as_global_rw(Ap->hmir)[((size_t)blockIdx.x * S + s) * NA + n] = hv;     // [stream][neuron]: one 64-byte line = 4 blocks
-                            }
                         }
                     }
                 }
@@ -1255,18 +1118,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             };
             {
                 constexpr int NI = NA * S, NQ_MAX = (NI + LPCN_WG_THREADS - 1) / LPCN_WG_THREADS;
-#ifndef LPCN_GATE_ROUNDS
-#define LPCN_GATE_ROUNDS 0      // 1: a wave skips the gate-stage rounds in which it has no item (S = 1, 2); 0: every wave runs every round.  Measured in round 5 (int8,
-                                // S = 2 x 2 workgroups per CU: 138 -> 69 VALU instructions on waves 4..7): 156.8 vs 157.9 M samples/s -- SLOWER; fp32 at 512 streams 74.8 vs 74.8.
-                                // The empty round's instructions are not what the phase waits for, and the wave-divergent paths cost more at the barrier than they save.
-#endif
-                if constexpr (NI % LPCN_WG_THREADS == 0 || !LPCN_GATE_ROUNDS) gate_stage(std::integral_constant<int, NQ_MAX>{});
-                else {
-                    // this wave's lanes are tid0 = 64 w .. 64 w + 63: round q holds items for it iff q * 512 + 64 w < NI
-                    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-                    if ((NQ_MAX - 1) * LPCN_WG_THREADS + wv * 64 < NI) gate_stage(std::integral_constant<int, NQ_MAX>{});
-                    else gate_stage(std::integral_constant<int, NQ_MAX - 1>{});
-                }
+                // (every wave runs every round: skipping a wave's empty rounds at S = 1, 2 was measured in round 5 and is slower -- 156.8 vs 157.9 M int8;
+                // the wave-divergent paths cost more at the barrier than the empty round's issue slots return)
+                gate_stage(std::integral_constant<int, NQ_MAX>{});
             }
             __syncthreads();                                                   // B2
             LPCN_PROF(1);
@@ -1436,13 +1290,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             constexpr bool GBMOVE = I8 && !FAST && S <= 2;
             constexpr int GBWA = GBMOVE ? LPCN_I8_GBWA : 0, GBWB = GBMOVE ? LPCN_I8_GBWB : 1;
             const bool gate_wave = gb_split ? (wave % GB_W == 0) : (GBMOVE ? (wave == GBWA || (S == 2 && wave == GBWB)) : wave < S);      // wave-uniform
-            if constexpr (!I8 && !FAST) {
-                if (gb_scalar) { ++gbseq; if (!gate_wave) mirror_arrive(); }
-            }
             float zrh = 0.f, rec = 0.f;
             const int s = gb_split ? wave / GB_W : (GBMOVE ? (wave == GBWA ? 0 : 1) : wave);     // (stream of a gate wave)
             const int r = lane < RB ? lane : RB - 1;
-            if (gb_prod || gb_ring) ++prseq;
+            if (gb_prod) ++prseq;
             if (gate_wave) {
                 // the longest chain of the sample: win issue arbitration against the early GRU-A slot sharing the SIMD
                 __builtin_amdgcn_s_setprio(3);                 // (priority 1 or none: the same step time, measured)
@@ -1527,32 +1378,10 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                         if constexpr (PACK2) {
                             // 128-VGPR variants (two workgroups per CU): the other workgroup hides the LDS latency, a
                             // two-quad pipeline is enough and keeps the kernel out of scratch memory
-#ifndef LPCN_I8_GB_DEPTH
-#define LPCN_I8_GB_DEPTH 3      // quads of GRU-B's ring on the 128-VGPR kernels: 2 / 3 / 4 -> 169.2 / 172.0 / 172.1 M samples/s (round 5, chain waves 2, 3; round 4, chain waves 0, 1: 2 and 3 equal)
-#endif
-#ifndef LPCN_I8_GB_ASM
-#define LPCN_I8_GB_ASM 0
-#endif
-                            if constexpr (LPCN_I8_GB_ASM) {
-                                // the hand-scheduled form of this loop (tools/gen_grub_asm.py --i8 96 --ring 3): the dots and conversions of quad q + 1 in the
-                                // shadow of the four dependent adds of quad q, reads two quads ahead; v96..v127 are named by the block
-                                uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(const unsigned char *)wq;
-                                uint32_t xp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(const unsigned char *)xq4;
-                                asm volatile(
-#include "grub_i8_loop.inc"
-                                    : [z] "+v"(zrh), [wp] "+v"(wp32), [xp] "+v"(xp32) : : LPCN_GRUB_I8_CLOBBERS_96);
-                            } else if constexpr (LPCN_I8_GB_DEPTH == 4) {     // reads three quads ahead
-                                i4 w0 = wq[0], x0 = xq4[0], w1 = wq[8], x1 = xq4[1], w2 = wq[16], x2 = xq4[2];
-#pragma unroll 4
-                                for (int q = 0; q < 24; ++q) {
-                                    const i4 w3 = wq[(q + 3) * 8], x3 = xq4[q + 3];     // (past the end on the last trips: padded / unused)
-                                    float d[4];
-                                    dot4_cvt_x4(d, w0[0], w0[1], w0[2], w0[3], x0[0], x0[1], x0[2], x0[3]);
-                                    zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3];
-                                    w0 = w1; x0 = x1; w1 = w2; x1 = x2; w2 = w3; x2 = x3;
-                                }
-                            } else if constexpr (LPCN_I8_GB_DEPTH == 3) {     // reads two quads ahead
-                                i4 w0 = wq[0], x0 = xq4[0], w1 = wq[8], x1 = xq4[1];
+                            // ring of three quads (reads two quads ahead): 2 / 3 / 4 quads -> 169.2 / 172.0 / 172.1 M samples/s in round 5; the hand-scheduled
+                            // assembly form of this loop (tools/gen_grub_asm.py --i8) was measured too: 168.4 vs 169.2 M, 15 more spilled VGPRs
+                            {
+                            i4 w0 = wq[0], x0 = xq4[0], w1 = wq[8], x1 = xq4[1];
 #pragma unroll 3
                                 for (int q = 0; q < 24; ++q) {
                                     const i4 w2 = wq[(q + 2) * 8], x2 = xq4[q + 2];     // (past the end on the last trips: padded / unused)
@@ -1561,16 +1390,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                                     zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3];
                                     w0 = w1; x0 = x1; w1 = w2; x1 = x2;
                                 }
-                            } else {
-                            i4 w0 = wq[0], x0 = xq4[0];
-#pragma unroll 2
-                            for (int q = 0; q < 24; ++q) {
-                                const i4 w1 = wq[(q + 1) * 8], x1 = xq4[q + 1];     // (past the end on the last trip: padded / unused)
-                                float d[4];
-                                dot4_cvt_x4(d, w0[0], w0[1], w0[2], w0[3], x0[0], x0[1], x0[2], x0[3]);
-                                zrh = zrh + d[0]; zrh = zrh + d[1]; zrh = zrh + d[2]; zrh = zrh + d[3];
-                                w0 = w1; x0 = x1;
-                            }
                             }
                         } else {
                         i4 wA[4], xA[4], wB[4], xB[4];
@@ -1627,23 +1446,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::bw + (sm_bstart[g] * 8 + ri) * 16 + ((0x321100 >> (4 * g)) & 15) * 128);
                     uint32_t hp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::hA + s * 16);
                     if constexpr (S == 4) {
-                      if (gb_ring) {
-                        // blocks 0 .. RING_FIRST - 1 as below, then the products that wave 4 + s has left in the ring
-                        asm volatile(
-#include "grub_lds_loop_s4_first.inc"
-                            : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS4F_CLOBBERS);
-                        prod_wait();
-                        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-                        uint32_t q0 = lds0 + L::pre + (s * L::RING_SEG0 * RB + r) * 16, q1 = lds0 + L::inh + (s * L::RING_SEG1 * RB + r) * 16;
-                        uint32_t q2 = lds0 + L::prod(Ap->nb_b, I8) + (s * L::RING_SEG2 * RB + r) * 16;
-                        asm volatile(
-#include "grub_ring_sum.inc"
-                            : [z] "+v"(zrh) : [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2) : LPCN_GRUB_RING_SUM_CLOBBERS);
-                      } else {
                         asm volatile(
 #include "grub_lds_loop_s4.inc"
                             : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
-                      }
                     } else if constexpr (S == 2) {
                         asm volatile(
 #include "grub_lds_loop_s2.inc"
@@ -1663,19 +1468,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #include "grub_lds_loop_s1.inc"
                             : [z] "+v"(zrh), [wp] "+v"(wp32), [hp] "+v"(hp32) : : LPCN_GRUB_LDS_CLOBBERS);
                     }
-                } else if (gb_scalar) {
-                    // state through SGPRs: the whole 96-block loop is one hand-scheduled assembly block (tools/gen_grub_asm.py)
-                    // (a ring of 8 sample slots with one s_dcache_inv per turn instead of one per sample was measured: 102.7 vs 104.9 M --
-                    // the larger footprint costs more in the 16 KB scalar cache than the invalidations do)
-                    const float *hb = Ap->hmir + ((size_t)blockIdx.x * S + s) * NA;
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) rec = rec + sm_brec[j * RB + r] * sm_hB[s * NB + j];
-                    mirror_arrive();
-                    mirror_wait();
-                    uint32_t wp32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(smem + L::bw + (sm_bstart[g] * 8 + ri) * 16);   // this lane's row, block 0 of its group
-                    asm volatile(
-#include "grub_scalar_loop.inc"
-                        : [z] "+v"(zrh), [wp] "+v"(wp32) : [hb] "s"(hb) : LPCN_GRUB_SCALAR_CLOBBERS);
                 } else {
                 // Each group's block list is padded to a multiple of 4 (zero weights) by the host.
                 // This phase runs one wave per SIMD, so latency must be hidden by software, and the
@@ -1762,24 +1554,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 prod_arrive();
-            } else if (gb_ring) {
-                // ---- four streams: wave 4 + s multiplies weight x state for the last RING_BLOCKS blocks of stream s and leaves the products in the ring
-                // (the same single multiply per term as the chain wave's own v_pk_mul_f32), then runs its candidate heads
-                if (LPCN_GRUB_RING == 2 && early_wave) run_head();      // (2: the products AFTER the heads, in the time the wave would otherwise wait for GRU-B)
-                if constexpr (S == 4) {
-                    const int ps = wave - LPCN_WAVES / 2;          // (every non-gate wave of a four-stream workgroup is one of 4..7)
-                    const int g = r >> 3, ri = r & 7;
-                    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-                    const uint32_t wp32 = lds0 + L::bw + (sm_bstart[g] * 8 + ri) * 16 + ((0x321100 >> (4 * g)) & 15) * 128;
-                    const uint32_t hp32 = lds0 + L::hA + ps * 16;
-                    const uint32_t q0 = lds0 + L::pre + (ps * L::RING_SEG0 * RB + r) * 16, q1 = lds0 + L::inh + (ps * L::RING_SEG1 * RB + r) * 16;
-                    const uint32_t q2 = lds0 + L::prod(Ap->nb_b, I8) + (ps * L::RING_SEG2 * RB + r) * 16;
-                    asm volatile(
-#include "grub_ring_fill.inc"
-                        : : [wp] "v"(wp32), [hp] "v"(hp32), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2) : LPCN_GRUB_RING_FILL_CLOBBERS);
-                    prod_arrive();
-                }
-                if (LPCN_GRUB_RING != 2 && early_wave) run_head();
             } else if (early_wave) {
                 // ---- the head of the next sample's candidate chains (runs in the shadow of GRU-B)
                 run_head();
@@ -1918,12 +1692,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             if (more) ++seq;
             unsigned long long t_b4 = 0;
             if (tracing_any) t_b4 = __builtin_amdgcn_s_memtime();                 // tests: leader latency barrier -> publish
-#ifndef LPCN_LEADER_PRIO
-#define LPCN_LEADER_PRIO 3
-#endif
             // the leader's dependent chain is what every other wave waits for: it wins issue arbitration against the wave that
             // shares its SIMD (which is already running next sample's candidate items at priority 2) until the indices are out
-            if (tid < 64 && LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(LPCN_LEADER_PRIO);
+            if (tid < 64) __builtin_amdgcn_s_setprio(3);
             if (tid < 16 * S) {
                 const int lrow = (tid & 63) >> 4, tap = tid & 15;
                 // (tried in round 5: the walk by the row's 16 lanes in two dependent steps -- lane c tests the c-th root-to-leaf path of a 4-level
@@ -1980,7 +1751,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
                 // the next sample's indices first: the other waves are waiting for them
                 if (more) { open_sample(live, pcm, tap == 0 ? pcm * lpc_tap : prod_old, exc, false); publish_indices(); }
-                if (LPCN_LEADER_PRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
                 if (tracing_lane0(live))
                     as_global_rw(Ap->dbg)[((size_t)f * LPCN_FRAME_SIZE + smp) * LPCN_DBG_STRIDE + 405] = (float)(unsigned)(__builtin_amdgcn_s_memtime() - t_b4);
                 if (tap == 0) {

@@ -26,12 +26,9 @@
 
 namespace lpcn {
 
-#ifndef LPCN_X2_LW
 #define LPCN_X2_LW 4            // the wave that leads the streams (tree walk, LPC predictor, mu-law): a head wave (model_pack.c gives it the shortest candidate slot) -- waves 0..3 start GRU-B's chains at once
-#endif
-#ifndef LPCN_X2_TW
-#define LPCN_X2_TW 5            // the wave that draws the KISS99 thresholds
-#endif
+#define LPCN_X2_TW 5            // the wave that draws the KISS99 thresholds      (leader on wave 5 / 7: 139.3 / 138.2 M samples/s against 146.7 M on wave 4, round 6)
+#define LPCN_X2_HG 10           // head items a row wave runs before it polls the leader's indices for the start-value pass (6 / 10 / 14 / 18: 145.0 / 146.7 / 146.2 / 144.3 M)
 
 struct LdsX2 {
     static constexpr int S = 4;
@@ -465,9 +462,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
         // ---------------------------------------------------------------- 2..4: P3 of group Q around P's start-value pass ----
         // The HEAD of group Q's next candidate chains: the first `hl` blocks of every row of this wave's candidate slot (items [NW - hl, NW)) from
         // bias + diag*h -- final once Q's gate stage is done -- parked in the rows' pre-activation cells; the slot continues from there in Q's next P1.
-#ifndef LPCN_X2_HG
-#define LPCN_X2_HG 10
-#endif
         constexpr int J0 = NW - LPCN_EARLY_MAX < 0 ? 0 : NW - LPCN_EARLY_MAX;
         constexpr int JM = J0 + LPCN_X2_HG < NW ? J0 + LPCN_X2_HG : NW;
         const bool do_heads = early_wave && q_heads;

@@ -22,16 +22,19 @@ sys.path.insert(0, ROOT)
 
 
 def compile_asm(s_value, out_path):
+    """s_value 1 / 2 / 4: sample_variants.hip with -DLPCN_S; 8: the two-group kernel (sample_x2.hip)"""
     from lpcnet_amd import build
-    cmd = [build.HIPCC] + build.HIP_FLAGS + [f"-DLPCN_S={s_value}", "--cuda-device-only", "-S",
-                                             os.path.join(build.CSRC, "sample_variants.hip"), "-o", out_path]
+    src = "sample_x2.hip" if s_value == 8 else "sample_variants.hip"
+    cmd = [build.HIPCC] + build.HIP_FLAGS + ([] if s_value == 8 else [f"-DLPCN_S={s_value}"]) + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out_path]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
 
 
 def demangle(name):
     m = re.match(r"_ZN4lpcn13sample_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)EEE", name)
-    return None if not m else dict(S=int(m.group(1)), NW=int(m.group(2)), int8=bool(int(m.group(3))), fast=bool(int(m.group(4))),
-                                   pack2=bool(int(m.group(5))))
+    if m:
+        return dict(S=int(m.group(1)), NW=int(m.group(2)), int8=bool(int(m.group(3))), fast=bool(int(m.group(4))), pack2=bool(int(m.group(5))))
+    m = re.match(r"_ZN4lpcn16sample_kernel_x2ILi(\d+)EEE", name)          # eight streams per workgroup (two groups of four)
+    return None if not m else dict(S=8, NW=int(m.group(1)), int8=False, fast=False, pack2=False)
 
 
 def analyse(asm_path):
@@ -41,7 +44,7 @@ def analyse(asm_path):
     bodies = {}
     cur = None
     for i, ln in enumerate(lines):
-        m = re.match(r"^(_ZN4lpcn13sample_kernel\w+):\s*(;.*)?$", ln)
+        m = re.match(r"^(_ZN4lpcn1[36]sample_kernel\w+):\s*(;.*)?$", ln)
         if m:
             cur = m.group(1)
             bodies[cur] = [i, None]
@@ -113,7 +116,7 @@ def analyse(asm_path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--s", type=int, default=4)
+    ap.add_argument("--s", type=int, default=4, help="streams per workgroup: 1, 2, 4, or 8 = the two-group kernel")
     ap.add_argument("--asm-dir", default=None)
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
