@@ -194,7 +194,7 @@ def test_bench_eight_rank_shape_rehearsed_on_one_gpu(flag):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-device", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline"] + flag, capture_output=True, text=True, env=env, timeout=1500)
+                        "--streams", "1024", "--no-cpu-baseline"] + flag, capture_output=True, text=True, env=env, timeout=1500)      # (configs 3 / 4: 8 x 1024; the bench's default is 2048 per GPU since round 6)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -1,0 +1,51 @@
+"""The JSON lines bench.py prints (GPU box): the default command's extra records and the real-time mode (the code that produces the
+real-time claim ran in no test, and the driver's line carried neither the measured sustained-stream figure nor BASELINE config 4's weights)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, timeout=1500):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_rt_mode_is_oracle_checked_and_carries_both_clocks():
+    """`bench.py --rt`: frame-at-a-time steps at two small stream counts -- the one-frame kernels at real-time grid shapes -- every step's wall AND device
+    time, the timed steps' output checked against the oracle"""
+    d = run_bench(["--rt", "--rt-sweep", "64,256", "--steps", "20"])
+    assert d["parity_checked"] > 0 and len(d["rt"]) == 2
+    for r in d["rt"]:
+        assert r["parity_checked"] > 0 and r["steps"] == 20
+        assert 0 < r["device_ms_p50"] <= r["step_ms_p50"] * 1.02 and r["device_ms_max"] >= r["device_ms_p50"]
+        assert r["step_ms_p99"] < 10.0 and r["meets_deadline_p99"] and r["over_deadline_steps"] == len(r["late_steps"]) == 0
+    assert d["realtime_streams_sustained"] == 256
+
+
+def test_default_line_shape_with_its_also_and_rt_records(monkeypatch):
+    """the driver's command (`python bench.py`, here with fewer steps and without the CPU baseline): headline on the two-group kernel, `also` (BASELINE config 2's
+    1024 streams, config 4's int8 weights), `rt` (measured sustained stream count), each oracle-checked"""
+    d = run_bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["parity_checked"] == 8 and d["config"]["streams_per_gpu"] == 2048
+    assert d["config"]["streams_per_workgroup"] == 8 and d["roofline"]["kernel"] == "lpcn::sample_kernel_x2"
+    assert d["roofline"]["frac"] > 0.2 and d["roofline"]["library_matches_sources"]
+    a = d["also"]
+    assert a["config2_1024_streams"]["parity_checked"] == 8 and a["config2_1024_streams"]["streams_per_workgroup"] == 4
+    assert a["int8_parity"]["parity_checked"] == 8 and a["int8_parity"]["value"] > a["config2_1024_streams"]["value"]
+    assert d["value"] > a["config2_1024_streams"]["value"]                                  # eight streams per CU beat four
+    rt = d["rt"]
+    assert len(rt["probe"]) == 2 and all(p["parity_checked"] > 0 for p in rt["probe"])
+    assert d["realtime_streams_sustained"] == rt["sustained_streams"] and rt["sustained_streams"] in (0, 7168, 8192)
+    assert rt["sustained_streams"] <= d["realtime_streams_by_division"]                     # a deadline cannot beat a division
