@@ -365,6 +365,8 @@ def main():
                          "(default: float32 weights, the configuration the metric is quoted on)")
     ap.add_argument("--densities", default="", help="GRU-A block densities 'z,r,h' of the synthetic model (default 0.05,0.05,0.2 = SURVEY.md section 8d); "
                     "e.g. 0.07,0.07,0.25 loads the 36-items-per-lane kernel, 0.08,0.08,0.3 the 40-item one (NOT the headline workload)")
+    ap.add_argument("--skew", type=float, default=0.0, help="trained-like (heavy-tailed) block distribution of the synthetic GRU-A: synth.make_model(skew=...), "
+                    "e.g. 0.1 -> row groups with up to 65 of 96 blocks, 48 empty ones (NOT the headline workload)")
     ap.add_argument("--rt", action="store_true",
                     help="the operating point the metric is NAMED after: frame-at-a-time synthesis (one lpcnet_synthesize per 10-ms frame and "
                          "stream, src/lpcnet_demo.c:203-219) of --streams concurrent streams against the 10-ms frame deadline -- every step is one "
@@ -402,12 +404,14 @@ def main():
     if a.rt:
         return rt_main(a, world, rank, local, dev)
 
-    def run_workload(n, F, int8, steps, warmup, fast=False, fp16_fc=False, spw=0, densities="", check_streams=8, seed0=1000):
+    def run_workload(n, F, int8, steps, warmup, fast=False, fp16_fc=False, spw=0, densities="", check_streams=8, seed0=1000, skew=0.0):
         """`warmup` untimed + `steps` timed passes of the hot path over n streams x F frames (features / PCM resident in HBM), then the live kernel
         timing and the checker leg; returns the figures of one workload."""
         mk = dict(flavour="int8" if int8 else "float")
         if densities:
             mk["densities"] = tuple(float(x) for x in densities.split(","))
+        if skew:
+            mk["skew"] = skew
         blob = synth.blob_bytes(synth.make_model(**mk))
         batch = api.LPCNetBatch(n, blob, device=local)
         if fast:
@@ -478,7 +482,7 @@ def main():
                 "parity_checked": parity_checked, "streams_per_workgroup": spw_used, "samples_per_step": samples_per_step, "blob": blob, "nb_a": int(api.check_model(blob)[1][1])}
 
     n, F = a.streams, a.frames
-    head = run_workload(n, F, a.int8, a.steps, a.warmup, fast=a.fast, fp16_fc=a.fp16_fc, spw=a.spw, densities=a.densities, check_streams=a.check_streams)
+    head = run_workload(n, F, a.int8, a.steps, a.warmup, fast=a.fast, fp16_fc=a.fp16_fc, spw=a.spw, densities=a.densities, check_streams=a.check_streams, skew=a.skew)
     value, ms_sample, ms_frame, parity_checked, samples_per_step, nb_a = (head[k] for k in ("value", "ms_sample", "ms_frame", "parity_checked", "samples_per_step", "nb_a"))
 
     def lds_frac(rec, int8):
@@ -486,7 +490,7 @@ def main():
 
     # ---- (N = 1, the default command only) what else the metric and BASELINE's configs name: config 2's 1024 streams, config 4's int8 weights, the deadline
     also, rt = None, None
-    default_cmd = world == 1 and not (a.fast or a.int8 or a.densities or a.spw) and (n, F) == (STREAMS_PER_GPU, FRAMES_PER_STEP) and not a.no_extras
+    default_cmd = world == 1 and not (a.fast or a.int8 or a.densities or a.spw or a.skew) and (n, F) == (STREAMS_PER_GPU, FRAMES_PER_STEP) and not a.no_extras
     if default_cmd:
         also = {}
         r1 = run_workload(CONFIG2_STREAMS, F, False, max(a.steps // 2, 2), 1, check_streams=a.check_streams, seed0=3000)
@@ -555,6 +559,7 @@ def main():
                                       "`also.config2_1024_streams`)" if x2 else ""),
                        "arithmetic": "fast" if a.fast else "parity",
                        "gru_a_blocks": nb_a, "gru_a_densities": a.densities or "0.05,0.05,0.2 (benchmark model)",
+                       "gru_a_skew": a.skew, "gru_a_items_per_lane": int(api.check_model(head["blob"])[1][3]),
                        "streams_per_gpu": n, "frames_per_step": F, "streams_per_workgroup": head["streams_per_workgroup"],
                        "sharding": f"{world} x {n} independent streams, no data-path collective"},
             "roofline": {"bound": "lds_operand_bandwidth", "kernel": "lpcn::sample_kernel_x2" if x2 else "lpcn::sample_kernel",

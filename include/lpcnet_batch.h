@@ -110,7 +110,8 @@ LPCNET_EXPORT int lpcnet_batch_export_state(LPCNetBatch *b, int stream, LPCNetSt
 LPCNET_EXPORT int lpcnet_batch_import_state(LPCNetBatch *b, int stream, const LPCNetState *st);
 
 /* Tuning / introspection */
-LPCNET_EXPORT int lpcnet_batch_set_streams_per_workgroup(LPCNetBatch *b, int s);      /* 1, 2, 4; 0 = auto */
+LPCNET_EXPORT int lpcnet_batch_set_streams_per_workgroup(LPCNetBatch *b, int s);      /* 1, 2, 4, 8; 0 = auto.  8 = the two-group kernel (float blobs with a dense GRU-B matrix and
+                                                                                        * <= 32 GRU-A items per lane, bit-exact arithmetic): chosen automatically beyond four streams per CU */
 LPCNET_EXPORT int lpcnet_batch_get_streams_per_workgroup(const LPCNetBatch *b);
 /* Streams per workgroup are measured on the batch itself (PARITY arithmetic; FAST takes a table value so that its output
  * never depends on timing): lpcnet_batch_tune() does it now, on the engine's own stream (~10 ms).  Without it the first

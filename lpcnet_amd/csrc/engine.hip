@@ -143,13 +143,12 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     }
     if (device < 0 || device >= ndev) { snprintf(g_err, sizeof(g_err), "bad device %d (have %d)", device, ndev); return LPCN_E_ARG; }
     // compiled item counts per lane: fp32 items are 4 VGPRs each, int8 items 1 VGPR
-    static const int variants_f32[] = {24, 28, 30, 32, 36, 40, 48, 0};
-    static const int variants_i8[] = {32, 48, 64, 0};
+    static const int variants_f32[] = {24, 28, 30, 32, 36, 40, 48, 64, 80, 96, 0};
+    static const int variants_i8[] = {32, 48, 64, 96, 0};
     int nwv = 0;
     for (const int *v = m->is_int8 ? variants_i8 : variants_f32; *v; ++v) if (m->nw <= *v) { nwv = *v; break; }
     if (!nwv) {
-        snprintf(g_err, sizeof(g_err), "GRU-A too dense for the register-resident kernel (needs %d items/lane, max %d)", m->nw,
-                 m->is_int8 ? 64 : 48);
+        snprintf(g_err, sizeof(g_err), "GRU-A does not fit the kernel's item variants (needs %d items on one lane, max 96: more than three full rows' worth of blocks on one wave)", m->nw);
         return LPCN_E_MODEL;
     }
     DeviceGuard guard(device);

@@ -318,7 +318,7 @@ static int pack_gru_a(lpcn_model_host *m, int for_fast)
     if (deal2) {                                    /* float blobs: the enumeration replaces the assignment above */
         int nc = 0, w2[NSLOT];
         while (nc < NSLOT && slot_allh[nc]) nc++;
-        static const int caps[] = {30, 32, 36, 40, 48, 64, 0};
+        static const int caps[] = {30, 32, 36, 40, 48, 64, 80, 96, 0};
         int done = 0;
         for (const int *c = caps; *c && !done; c++) {
             if (slot_max[0] > *c) continue;

@@ -349,7 +349,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     constexpr int WSD = 4;
     WT w[NR];
     WT ws[NR < NW ? WSD : 1] = {};
-    uint32_t offp[(NW + 1) / 2];
+    // LDS offsets of the items' state blocks, two per register -- of the RESIDENT items; a streamed item's block index is re-fetched with it (one byte
+    // per lane and item from a_blk, WSOD - 1 items ahead of its state read): 64 / 80 items per lane would otherwise hold 32 / 40 registers of offsets
+    // (round 6: heavy-tailed, trained-like sparsity needs those variants)
+    constexpr int WSOD = 8;
+    constexpr bool OFFB = I8 && NW > 64;                     // int8 blobs, 96 items per lane: the block INDICES, four per register (48 registers of offsets do not fit beside 96 of weights)
+    uint32_t offp[OFFB ? (NW + 3) / 4 : (NR + 1) / 2];
+    int wso[NR < NW ? WSOD : 1] = {};
     int row_reg[3];
 #define LPCN_ROW(k) (row_reg[k])
     {
@@ -369,10 +375,19 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 w[j] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+        if constexpr (OFFB) {
 #pragma unroll
-        for (int j = 0; j < NW; j += 2) {
+            for (int j = 0; j < NW; j += 4) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pk |= (uint32_t)((j + k < NW) ? ab[base + (size_t)(j + k) * 64] : 0) << (8 * k);
+                offp[j >> 2] = pk;
+            }
+        } else
+#pragma unroll
+        for (int j = 0; j < NR; j += 2) {
             const int p0 = ab[base + (size_t)j * 64];
-            const int p1 = (j + 1 < NW) ? ab[base + (size_t)(j + 1) * 64] : 0;
+            const int p1 = (j + 1 < NR) ? ab[base + (size_t)(j + 1) * 64] : 0;
             // (I8M: lane k of a quad fetches only stream k's dword -- the matrix pipe forms all (stream, row) pairs of the quad)
             if constexpr (I8M) offp[j >> 1] = (uint32_t)(p0 * 4 * S + (lane & (S - 1)) * 4) | ((uint32_t)(p1 * 4 * S + (lane & (S - 1)) * 4) << 16);
             else if constexpr (I8) offp[j >> 1] = (uint32_t)(p0 * 4 * S) | ((uint32_t)(p1 * 4 * S) << 16);
@@ -406,7 +421,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
         asm volatile("" : "+s"(fc_w_s), "+s"(fc_b_s), "+s"(fc_f_s));
     }
     const LPCN_GLOBAL char *aw_s = (const LPCN_GLOBAL char *)as_global(Ap->a_w);       // item array, for the streamed items (NR < NW)
-    if constexpr (NR < NW) asm volatile("" : "+s"(aw_s));
+    const LPCN_GLOBAL uint8_t *ab_s = as_global(Ap->a_blk);                             // ... and their block indices
+    if constexpr (NR < NW) asm volatile("" : "+s"(aw_s), "+s"(ab_s));
 #define fc_w_g fc_w_s
 #define fc_b_g fc_b_s
 #define fc_f_g fc_f_s
@@ -722,10 +738,32 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             // state blocks are fetched PF items ahead of their use
             constexpr int PF = 2;                            // (1 / 2 / 3 items ahead: 124.4 / 124.8 / 125.1 M in round 4 -- noise)
             HT hq[PF + 1] = {};
+            auto fetch_o = [&](const int j) {                // streamed item j's block index -> its ring slot (one byte per lane, from L2)
+                if constexpr (NR < NW) {
+                    uint32_t bo = (uint32_t)tid0;
+                    LPCN_REMAT_V(bo);
+                    bo = (bo >> 6) * (uint32_t)(NW * 64) + (bo & 63u) + (uint32_t)j * 64u;
+                    wso[(j - NR) % WSOD] = ab_s[bo];
+                }
+            };
             auto fetch_h = [&](const int j) {
-                uint32_t pk = offp[j >> 1];
-                LPCN_REMAT_V(pk);                            // keep the unpack inside the sample loop
-                const uint32_t off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
+                uint32_t off;
+                if (NR < NW && j >= NR) {                    // (float blobs only: int8 items are all resident)
+                    uint32_t pb = (uint32_t)wso[(j >= NR ? j - NR : 0) % WSOD], ls = (uint32_t)tid0;
+                    LPCN_REMAT_V(ls);
+                    ls = (S >= 4 ? (ls & 3u) : (S == 2 ? (ls & 1u) : 0u)) * 16u;
+                    off = pb * (uint32_t)L::HA_STRIDE + (pb >> 2) * 16u + ls;
+                } else if constexpr (OFFB) {
+                    uint32_t pk = offp[j >> 2];
+                    LPCN_REMAT_V(pk);
+                    const uint32_t pb = (pk >> (8 * (j & 3))) & 0xFFu;
+                    if constexpr (I8M) { uint32_t ls = (uint32_t)tid0; LPCN_REMAT_V(ls); off = pb * (4u * S) + (ls & (uint32_t)(S - 1)) * 4u; }
+                    else off = pb * (4u * S);
+                } else {
+                    uint32_t pk = offp[(j < NR ? j : 0) >> 1];
+                    LPCN_REMAT_V(pk);                        // keep the unpack inside the sample loop
+                    off = (j & 1) ? (pk >> 16) : (pk & 0xFFFFu);
+                }
                 hq[j % (PF + 1)] = *(const HT *)(smem + L::hA + off);
             };
             auto fetch_w = [&](const int j) {                // streamed item j -> its ring slot (one global_load_dwordx4 per lane: 1 KB per wave, from L2)
@@ -920,12 +958,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 // bookkeeping degrades to full waits and the state prefetch no longer overlaps anything)
                 constexpr int J0 = NW - LPCN_EARLY_MAX < 0 ? 0 : NW - LPCN_EARLY_MAX;
 #pragma unroll
+                for (int j = J0; j < J0 + WSOD - 1; ++j) if (NR < NW && j >= NR && j < NW) fetch_o(j);
+#pragma unroll
                 for (int j = 0; j < PF; ++j) if (J0 + j < NW) fetch_h(J0 + j);
 #pragma unroll
                 for (int j = J0; j < J0 + WSD - 1; ++j) if (NR < NW && j >= NR && j < NW) fetch_w(j);
                 auto step = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
                     constexpr int j = decltype(jc)::value;
                     if constexpr (j < NW) {
+                        if constexpr (NR < NW && j + WSOD - 1 >= NR && j + WSOD - 1 < NW) fetch_o(j + WSOD - 1);
                         if constexpr (j + PF < NW) fetch_h(j + PF);
                         if constexpr (NR < NW && j + WSD - 1 >= NR && j + WSD - 1 < NW) fetch_w(j + WSD - 1);
                         if (j >= e0) { asm volatile(""); mac(j); }       // (the empty statement keeps this a scalar branch: if-converted, int8 items became
@@ -989,6 +1030,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     }
                 }
                 if (__builtin_expect(j >= jend, 0)) return false;
+                if (NR < NW && j + WSOD - 1 >= NR && j + WSOD - 1 < NW) fetch_o(j + WSOD - 1);
                 if (j + PF < NW) fetch_h(j + PF);
                 if (NR < NW && j + WSD - 1 >= NR && j + WSD - 1 < NW) fetch_w(j + WSD - 1);
                 // slot boundaries (a slot may be empty: b1 == b2, or b1 == 0): ONE scalar compare per item against the next one

@@ -48,7 +48,8 @@ static int pick(int nw, int is_int8, int pack2, int grid, int lds, hipStream_t s
         switch (nw) {
         case 32: return (pack2 && LPCN_S <= 2) ? launch<32, true, FAST, (LPCN_S <= 2)>(grid, lds, st, d_args) : launch<32, true, FAST>(grid, lds, st, d_args);
         case 48: return launch<48, true, FAST>(grid, lds, st, d_args);
-        default: return launch<64, true, FAST>(grid, lds, st, d_args);
+        case 64: return launch<64, true, FAST>(grid, lds, st, d_args);
+        default: return launch<96, true, FAST>(grid, lds, st, d_args);      // (a row group may list every one of its 96 input blocks: trained, heavy-tailed sparsity)
         }
     }
     switch (nw) {
@@ -58,7 +59,10 @@ static int pick(int nw, int is_int8, int pack2, int grid, int lds, hipStream_t s
     case 32: return launch<32, false, FAST>(grid, lds, st, d_args);
     case 36: return launch<36, false, FAST>(grid, lds, st, d_args);
     case 40: return launch<40, false, FAST>(grid, lds, st, d_args);
-    default: return launch<48, false, FAST>(grid, lds, st, d_args);      // (more than 32 items per lane: the items past the 28th are streamed from L2, sample_kernel.hip.h)
+    case 48: return launch<48, false, FAST>(grid, lds, st, d_args);      // (more than 32 items per lane: the items past the 28th are streamed from L2, sample_kernel.hip.h)
+    case 64: return launch<64, false, FAST>(grid, lds, st, d_args);
+    case 80: return launch<80, false, FAST>(grid, lds, st, d_args);
+    default: return launch<96, false, FAST>(grid, lds, st, d_args);      // (a full row: every one of its 96 input blocks)
     }
 #endif
 }

@@ -91,13 +91,17 @@ def _quantize_matrix(w):
     return (q / 128.0).astype(np.float32), q
 
 
-def _block_sparsify(A, density):
+def _block_sparsify(A, density, group_gain=None):
     """lpcnet.py:96-116 restated in the exporter's orientation: A is [in N][out N] for one gate;
-    keep the top-`density` fraction of 4(in) x 8(out) blocks by energy (diagonal excluded)."""
+    keep the top-`density` fraction of 4(in) x 8(out) blocks by energy (diagonal excluded).
+    group_gain [N/8]: per output row group, a factor on the block energies the selection sees (the weights themselves are not scaled) --
+    a stand-in for what TRAINED weights do to the sparsifier: some output units keep most of their inputs, others almost none."""
     N = A.shape[0]
     Ad = A - np.diag(np.diag(A))
     L = Ad.reshape(N // 4, 4, N // 8, 8)
     S = (L * L).sum(axis=3).sum(axis=1)                  # [N/4][N/8]
+    if group_gain is not None:
+        S = S * (np.asarray(group_gain, A.dtype)[None, :] ** 2)
     SS = np.sort(S.reshape(-1))
     thresh = SS[int(round(N * N // 32 * (1 - density)))]
     mask = (S >= thresh).astype(A.dtype)
@@ -129,11 +133,15 @@ def _sparse_blocks(A, q):
 
 
 def make_model(seed=1234, flavour="float", shaped=True, densities=(0.05, 0.05, 0.2),
-               lpc_gamma=1.0, grub_density=1.0, off_grid=False):
+               lpc_gamma=1.0, grub_density=1.0, off_grid=False, skew=0.0):
     """Build the synthetic model.  The *same* seed gives the same network in both flavours
     (weights are snapped to k/128); only the qweight element type / blocking differs.
     off_grid=True (float flavour only) nudges the non-zero GRU weights off the k/128 grid, like a model trained
-    without quantisation."""
+    without quantisation.
+    skew > 0: TRAINED-LIKE block distribution of GRU-A -- the same number of blocks per gate (training_tf2/lpcnet.py:73-129 keeps the top-density
+    fraction of a gate's blocks), but their count per 8-row group is heavy-tailed instead of near-uniform: the selection sees each row group's
+    block energies through a log-normal gain exp(skew * N(0, 1)), so some candidate-gate groups keep 50-80 of their 96 possible blocks and others
+    none (i.i.d. random weights give every group of a gate about the same count, which no trained model does; SURVEY section 7, hard part 3)."""
     assert flavour in ("float", "int8")
     rng = np.random.default_rng(seed)
     f32 = np.float32
@@ -220,10 +228,19 @@ def make_model(seed=1234, flavour="float", shaped=True, densities=(0.05, 0.05, 0
     A = normal((N_A, 3 * N_A), 1.0)
     gate_sigma = (0.30, 0.30, 0.22)
     diag = []
+    skew_rng = np.random.default_rng(seed + 7919)         # (its own generator: the other weights of the model do not depend on `skew`)
     for k in range(3):
         Ak = A[:, k * N_A:(k + 1) * N_A] * gate_sigma[k]
         diag.append(_snap(np.diag(Ak) * 1.5))
-        A[:, k * N_A:(k + 1) * N_A] = _block_sparsify(Ak, densities[k])
+        gain = np.exp(skew * skew_rng.standard_normal(N_A // 8)) if skew > 0 else None
+        Ak = _block_sparsify(Ak, densities[k], gain)
+        if skew > 0:
+            # a row that keeps 60 blocks instead of 19 sums 3 x as many terms: scale the kept weights of a row group so that its pre-activation
+            # keeps about the variance of the uniform model's rows (trained weights of well-connected units are smaller, too)
+            cnt = (np.abs(Ak).reshape(N_A // 4, 4, N_A // 8, 8).sum(axis=(1, 3)) > 0).sum(axis=0)          # blocks per row group
+            scale = np.sqrt(max(densities[k] * (N_A // 4), 1.0) / np.maximum(cnt, 1.0))
+            Ak = Ak * np.repeat(np.minimum(scale, 1.5), 8)[None, :].astype(f32)
+        A[:, k * N_A:(k + 1) * N_A] = Ak
     A, QA = _quantize_matrix(A)
     W0, W, idx = _sparse_blocks(A, QA)
     m.add("sparse_gru_a_recurrent_weights_diag", np.concatenate(diag), WEIGHT_TYPE_FLOAT)

@@ -455,6 +455,34 @@ def test_other_model_shapes_match_oracle(kw, hip_lib):
         b.close()
 
 
+@pytest.mark.parametrize("kw", [dict(skew=0.1), dict(skew=0.15), dict(skew=0.1, flavour="int8"), dict(skew=0.4)],
+                         ids=["skew0.1", "skew0.15", "skew0.1-int8", "skew0.4-full-rows"])
+def test_trained_like_skewed_sparsity_loads_and_matches_the_oracle(kw, hip_lib):
+    """the sparsifier acts on TRAINED weights in the reference (training_tf2/lpcnet.py:73-129) and the block count per row group is
+    heavy-tailed there; the synthetic default (i.i.d. weights) gives every group of a gate about the same count.  synth.make_model(skew=...) keeps the
+    number of blocks per gate and makes their distribution over the row groups log-normal: groups with 65 / 74 / all 96 of their possible blocks,
+    dozens of empty ones.  Such models used to be REFUSED at load (more than 48 items on a lane); they run on the 64 / 80 / 96-item variants (28 items
+    resident, the rest and their block indices streamed from L2) and must match the oracle bit for bit like any other."""
+    m = synth.make_model(**kw)
+    blob = synth.blob_bytes(m)
+    rc, info = api.check_model(blob)
+    assert rc == 0 and info[5] == 0 and info[1] == 1382
+    assert info[3] > 48                                                  # (the model really needs one of the new variants)
+    n, T = 5, 6
+    feats = feats_for(range(2900, 2900 + n), T)
+    want, states = oracle_run(blob, feats)
+    for S in (1, 4):
+        b = api.LPCNetBatch(n, blob)
+        b.streams_per_workgroup = S
+        got = b.synthesize(feats)
+        assert np.array_equal(got, want), (kw, S)
+        st = b.get_state(n - 1)
+        _, _, ga, gb = states[n - 1].nnet_state()
+        assert np.array_equal(np.array(st.gru_a, np.float32), ga) and np.array_equal(np.array(st.gru_b, np.float32), gb)
+        b.close()
+    assert np.any(want[:, 320:] != 0)
+
+
 def test_plc_facing_entry_points(blob_f32, hip_lib):
     """the reference's internal entry points (src/lpcnet_private.h:125-132), which src/lpcnet_plc.c drives:
     split frame-network / tail calls, the deferred feature queue, teacher forcing and reset_signal"""

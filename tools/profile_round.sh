@@ -6,7 +6,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-RND=${1:-r05}
+RND=${1:-r06}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 # kernel stats + HBM traffic first: bench.py quotes `roofline.traffic` from profiles/<round>_hbm_traffic*.json, which must have been
@@ -16,24 +16,28 @@ rm -rf $OUT; mkdir -p $OUT
 for fl in f32 i8 f32_fast i8_fast; do
   case $fl in f32) flag="";; i8) flag="--int8";; f32_fast) flag="--fast";; i8_fast) flag="--int8 --fast --spw 2";; esac
   if [ $fl = f32 ] || [ $fl = i8 ]; then
-    LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/stats_$fl.log 2>&1
+    LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $flag > $OUT/stats_$fl.log 2>&1
   fi
-  LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/fetch_$fl.log 2>&1
-  LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > $OUT/write_$fl.log 2>&1
+  LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $flag > $OUT/fetch_$fl.log 2>&1
+  LPCNET_HIP_NO_AUTOTUNE=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$fl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $flag > $OUT/write_$fl.log 2>&1
 done
 python tools/profile_summarize.py $RND > /dev/null 2>&1
 timeout 600 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err
 timeout 300 python bench.py --int8 > $OUT/bench_i8.json 2> $OUT/bench_i8.err
 timeout 300 python bench.py --streams 1 --no-cpu-baseline > $OUT/bench_single.json 2> $OUT/bench_single.err      # BASELINE config 1
 # the operating point the metric is named after: one frame per step for every stream against the 10-ms deadline, >= 500 steps
-timeout 600 python bench.py --rt --steps 500 --rt-sweep 1024,4096,7168,7424,7680,8192 --no-cpu-baseline > $OUT/bench_rt_f32.json 2> $OUT/bench_rt_f32.err
-timeout 600 python bench.py --rt --steps 500 --rt-sweep 1024,8192,9216,9728,10240,10752 --no-cpu-baseline --int8 > $OUT/bench_rt_int8.json 2> $OUT/bench_rt_int8.err
+# (round 6, VERDICT r5 item 3: 2000 consecutive steps at the sustained counts, wall AND device time of every step)
+timeout 900 python bench.py --rt --steps 2000 --rt-sweep 1024,6144,7168,8192 --no-cpu-baseline > $OUT/bench_rt_f32.json 2> $OUT/bench_rt_f32.err
+timeout 900 python bench.py --rt --steps 2000 --rt-sweep 1024,10240,10752 --no-cpu-baseline --int8 > $OUT/bench_rt_int8.json 2> $OUT/bench_rt_int8.err
+# trained-like (heavy-tailed) GRU-A sparsity: the 80-item variants, items past the 28th and their block indices streamed from L2
+timeout 300 python bench.py --skew 0.1 --no-cpu-baseline > $OUT/bench_skewed.json 2> $OUT/bench_skewed.err
+timeout 300 python bench.py --skew 0.1 --int8 --no-cpu-baseline > $OUT/bench_skewed_int8.json 2> $OUT/bench_skewed_int8.err
 # denser GRU-A models: the variants that stream their items past the 28th from L2
 for dn in nw32:0.06,0.06,0.22 nw36:0.07,0.07,0.25 nw40:0.08,0.08,0.3 nw48:0.1,0.1,0.35; do
   timeout 300 python bench.py --densities ${dn#*:} --no-cpu-baseline > $OUT/bench_denseA_${dn%%:*}.json 2> $OUT/bench_denseA_${dn%%:*}.err
 done
 # throughput at other batch sizes
-for ns in 256 512 2048 4096 8192; do
+for ns in 256 512 1024 1536 4096 8192; do
   timeout 300 python bench.py --streams $ns --no-cpu-baseline --steps 6 --warmup 2 > $OUT/bench_f32_n$ns.json 2> $OUT/bench_f32_n$ns.err
   timeout 300 python bench.py --streams $ns --no-cpu-baseline --steps 6 --warmup 2 --int8 > $OUT/bench_i8_n$ns.json 2> $OUT/bench_i8_n$ns.err
 done
@@ -48,10 +52,12 @@ timeout 900 python bench.py --gpus 8 --share-device --steps 3 --warmup 1 --no-cp
 # BASELINE configs 0 -> 1: the reference's own demo on the engine vs its AVX2 builds, one 10-s feature file (wall seconds incl. process start)
 python tools/rtf_demo.py > $OUT/rtf_demo.json 2> $OUT/rtf_demo.err
 python tools/profile_sq.py --tag $RND > $OUT/sq_f32.log 2>&1
+python tools/profile_sq.py --tag ${RND}_n1024 --extra="--streams 1024" > $OUT/sq_f32_n1024.log 2>&1
 python tools/profile_sq.py --tag $RND --extra=--fast > $OUT/sq_f32_fast.log 2>&1
 python tools/profile_sq.py --int8 --tag $RND > $OUT/sq_i8.log 2>&1
 # in-kernel s_memtime phase tables (profiling build of the library: LPCN_PROF_MASK=0xFFF python -m lpcnet_amd.build --prof)
 if [ -f lpcnet_amd/liblpcnet_hip_prof.so ]; then
+  LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/x2_phase.py 12 2048 > $OUT/phase_x2.log 2>&1
   LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1:1 > $OUT/phase_f32.log 2>&1
   LPCN_FLAVOUR=int8 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4,1024:2 > $OUT/phase_i8.log 2>&1
   LPCN_FAST=1 LPCNET_HIP_LIB=$PWD/lpcnet_amd/liblpcnet_hip_prof.so python tests/tools/gpu_sweep.py 22 1024:4 > $OUT/phase_f32_fast.log 2>&1

@@ -63,7 +63,7 @@ def main():
         open(os.path.join(out_dir, "counters_available.txt"), "w").write(txt)
     rows = collections.OrderedDict()
     ndisp = 0
-    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + (["--int8"] if a.int8 else []) + a.extra.split()
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"] + (["--int8"] if a.int8 else []) + a.extra.split()
     for gi, group in enumerate(WISH):
         ctrs = [c for c in group if have is None or len(have) < 1000 or re.search(r"\b" + c + r"\b", have)]
         if not ctrs:
@@ -90,8 +90,8 @@ def main():
                 ndisp = cnt[c]
     path = os.path.join(out_dir, f"{a.tag}_sq_{fl}.csv")
     with open(path, "w") as o:
-        o.write(f"# rocprofv3 --pmc <<=8 SQ counters per pass> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline{' --int8' if a.int8 else ''} {a.extra}\n")
-        o.write(f"# lpcn::sample_kernel, per-dispatch average over {ndisp} dispatches (1024 streams x 25 frames x 160 samples per dispatch); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles\n")
+        o.write(f"# rocprofv3 --pmc <<=8 SQ counters per pass> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras{' --int8' if a.int8 else ''} {a.extra}\n")
+        o.write(f"# lpcn::sample_kernel*, per-dispatch average over {ndisp} dispatches (bench.py's workload: 2048 streams x 25 frames x 160 samples per dispatch unless --streams says otherwise); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles\n")
         o.write("counter,value_per_dispatch\n")
         for k, v in rows.items():
             o.write(f"{k},{v:.1f}\n")

@@ -4,7 +4,7 @@ import csv, glob, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_hash: ties the PMC numbers to the kernel sources they were measured with)
 
@@ -45,7 +45,7 @@ for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast"), ("i8_fas
             rows.append((k, len(full), sum(full), sum(full) / len(full), min(full), max(full), len(v) - len(full)))
         tot = sum(r[2] for r in rows) or 1
         with open(os.path.join(DST, f"{RND}_kernel_stats{suffix}.csv"), "w") as o:
-            o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline" + (" --int8" if fl == "i8" else "")
+            o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras" + (" --int8" if fl == "i8" else "")
                     + " (LPCNET_HIP_NO_AUTOTUNE=1); per kernel the workload's launches only (Dropped = shorter launches left out)\n")
             o.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","Dropped"\n')
             for k, n, t, avg, mn, mx, dropped in sorted(rows, key=lambda r: -r[2]):
@@ -55,9 +55,9 @@ for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast"), ("i8_fas
     fe, wr = counter_avg(f"fetch_{fl}", "FETCH_SIZE"), counter_avg(f"write_{fl}", "WRITE_SIZE")
     if fe and wr:
         with open(os.path.join(DST, f"{RND}_pmc_hbm_summary{suffix}.csv"), "w") as o:
-            o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+            o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
                     + {"f32": "", "i8": " --int8", "f32_fast": " --fast", "i8_fast": " --int8 --fast --spw 2"}[fl] + ", MI355X\n")
-            o.write("# workload per launch: 1024 streams x 25 frames x 160 samples; values are per-dispatch averages in KB as reported\n")
+            o.write("# workload per launch: 2048 streams x 25 frames x 160 samples; values are per-dispatch averages in KB as reported\n")
             o.write("kernel,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg\n")
             for k in sorted(fe):
                 o.write(f"{k},{fe[k][1]},{fe[k][0]:.1f},{wr.get(k, (0, 0))[0]:.1f}\n")
@@ -67,7 +67,7 @@ for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast"), ("i8_fas
             json.dump({"kernel": k, "kernel_source_hash": bench.kernel_source_hash(), "fetch_size_kb": fe[k][0], "write_size_kb": wr[k][0],
                        "hbm_bytes_per_launch": (2 * fe[k][0] + wr[k][0]) * 1024,
                        "correction": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
-                       "launch": "1024 streams x 25 frames x 160 samples = 4 096 000 output samples",
+                       "launch": "2048 streams x 25 frames x 160 samples = 8 192 000 output samples",
                        "command": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace)"},
                       open(os.path.join(DST, f"{RND}_hbm_traffic{suffix}.json"), "w"), indent=1)
 for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_fast.json", "bench_n1_fast.json"),
@@ -76,6 +76,7 @@ for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_
                  ("bench_rehearsal_2ranks.json", "bench_rehearsal_2ranks_one_gpu.json"), ("bench_rehearsal_8ranks.json", "bench_rehearsal_8ranks_one_gpu.json"),
                  ("bench_rehearsal_8ranks_int8.json", "bench_rehearsal_8ranks_one_gpu_int8.json"),
                  ("bench_rt_f32.json", "bench_rt_f32.json"), ("bench_rt_int8.json", "bench_rt_int8.json"),
+                 ("bench_skewed.json", "bench_n1_skewed.json"), ("bench_skewed_int8.json", "bench_n1_skewed_int8.json"),
                  ("bench_denseA_nw32.json", "bench_n1_denseA_nw32.json"), ("bench_denseA_nw36.json", "bench_n1_denseA_nw36.json"),
                  ("bench_denseA_nw40.json", "bench_n1_denseA_nw40.json"), ("bench_denseA_nw48.json", "bench_n1_denseA_nw48.json")):
     b = os.path.join(SRC, src)
@@ -86,7 +87,7 @@ for src, dst in (("bench_single.json", "bench_single_stream.json"), ("bench_f32_
 # throughput at other batch sizes: one file, one bench line per (flavour, stream count)
 sweep = []
 for fl in ("f32", "i8"):
-    for ns in (256, 512, 2048, 4096, 8192):
+    for ns in (256, 512, 1024, 1536, 2048, 4096, 8192):
         b = os.path.join(SRC, f"bench_{fl}_n{ns}.json")
         if os.path.exists(b) and os.path.getsize(b):
             js = [ln for ln in open(b).read().split("\n") if ln.startswith("{") and ln.rstrip().endswith("}")]
@@ -94,6 +95,18 @@ for fl in ("f32", "i8"):
                 sweep.append(js[-1])
 if sweep:
     open(os.path.join(DST, f"{RND}_bench_stream_sweep.jsonl"), "w").write("\n".join(sweep) + "\n")
+b1024 = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_n1024_sq_f32.csv")
+if os.path.exists(b1024):
+    shutil.copy(b1024, os.path.join(DST, f"{RND}_sq_counters_n1024.csv"))
+px2 = os.path.join(SRC, "phase_x2.log")
+if os.path.exists(px2):
+    with open(os.path.join(DST, f"{RND}_phase_clocks_x2.txt"), "w") as o:
+        o.write("# two-group sample kernel (sample_kernel_x2.hip.h): in-kernel s_memtime phase table of workgroup 0 (profiling build; LPCNET_HIP_LIB=.../liblpcnet_hip_prof.so\n"
+                "# python tests/tools/x2_phase.py 12 2048), shader clocks per HALF-step; the instrumentation costs ~15 % here (11 clock reads per half-step)\n"
+                "# columns: lead = top of the half-step (leader / thresholds / frame boundary); chain = GRU-B mat-vec; gatesB = its gates; heads = candidate heads of the other group;\n"
+                "# start = start-value pass (waves 4..7: wait for the indices + 3 + 1.5 rounds of loads) + wait for its counter + the slots' start values; items; close;\n"
+                "# tree = dual-FC prefetch wait + the tree of the other group (in front of the barrier); B1wait; P2 = gate stage; B2wait\n")
+        o.write(open(px2).read())
 for fl, suffix in (("f32", ""), ("i8", "_int8"), ("f32_fast", "_fast_f32")):
     b = os.path.join(ROOT, "gpurun_out", "sq", f"{RND}_sq_{fl}.csv")
     if os.path.exists(b):
