@@ -213,6 +213,42 @@ def kernel_source_hash():
     return build.source_hashes()[1]
 
 
+def fast_envelope_check(blob, feats, int8, fp16_fc, spw, device):
+    """FAST lines carry their own check: FAST is not bit-identical to any reference build, so it is validated TEACHER-FORCED -- a PARITY engine
+    and a FAST engine are fed the same signal (PARITY's free-running output for these very streams' feature files) frame by frame through the preload of
+    lpcnet_synthesize_impl (src/lpcnet.c:256-259), and the per-frame maximum state deviation must stay inside what the reference's own AVX2 builds show against its
+    generic-C builds under the same protocol (tests/golden/simd_envelope_v1.json, tests/tools/make_envelope.py; 1.25 x for the shorter run, like tests/test_gpu_fast.py).
+    Returns (streams checked, worst GRU-A deviation, worst GRU-B deviation); raises if the envelope is exceeded."""
+    from lpcnet_amd import api
+    env = json.load(open(os.path.join(ROOT, "tests", "golden", "simd_envelope_v1.json")))["int8" if int8 else "float"]
+    k, T = feats.shape[0], feats.shape[1]
+    ref = api.LPCNetBatch(k, blob, device=device)
+    pcm = ref.synthesize(feats)
+    ref.close()
+
+    def forced(fast):
+        b = api.LPCNetBatch(k, blob, device=device)
+        if spw in (1, 2, 4):
+            b.streams_per_workgroup = spw
+        if fast:
+            b.set_fast(2 if fp16_fc else 1)
+        ga, gb = np.zeros((T, k, 384), np.float32), np.zeros((T, k, 16), np.float32)
+        for t in range(T):
+            b.synthesize(np.ascontiguousarray(feats[:, t:t + 1]), preload_pcm=np.ascontiguousarray(pcm[:, t * 160:(t + 1) * 160]), preload=160)
+            for i in range(k):
+                st = b.get_state(i)
+                ga[t, i] = np.array(st.gru_a, np.float32)
+                gb[t, i] = np.array(st.gru_b, np.float32)
+        b.close()
+        return ga, gb
+    (ga_p, gb_p), (ga_f, gb_f) = forced(False), forced(True)
+    da = float(np.abs(ga_f - ga_p)[3:].max())
+    db = float(np.abs(gb_f - gb_p)[3:].max())
+    if not (np.abs(ga_p[3:]).max() > 0.3 and da <= 1.25 * env["gru_a"]["worst"] and (fp16_fc or db <= 1.25 * env["gru_b"]["worst"])):
+        raise SystemExit(f"bench.py --fast: teacher-forced state deviation outside the reference's own SIMD envelope (GRU-A {da:.3g} / {env['gru_a']['worst']:.3g}, GRU-B {db:.3g} / {env['gru_b']['worst']:.3g})")
+    return k, da, db
+
+
 FRAME_DEADLINE_MS = 10.0                # one frame = 160 samples at 16 kHz
 RT_PROBE_STREAMS = [7168, 8192]         # the default line's real-time probe: the counts that bracket the frame deadline (eight streams per CU: capacity moves in rounds of 2048)
 RT_PROBE_STEPS = 200
@@ -477,9 +513,17 @@ def main():
             parity_checked = len(pick)
         spw_used = batch.streams_per_workgroup
         batch.close()
+        envelope = None
+        if fast and rank == 0 and a.check_streams > 0:       # FAST: its own check on a few streams of this very batch (their feature files), teacher-forced
+            kk = min(4, n)
+            pick = sorted({(i * n) // kk for i in range(kk)})
+            ek, eda, edb = fast_envelope_check(blob, np.ascontiguousarray(feats[pick]), int8, fp16_fc, spw_used, local)
+            envelope = {"envelope_checked": ek, "max_gru_a_deviation": eda, "max_gru_b_deviation": edb,
+                        "protocol": "teacher-forced against the PARITY engine, limits = the reference's AVX2-vs-generic-C envelope (tests/golden/simd_envelope_v1.json x 1.25)"}
         samples_per_step = n * F * 160
         return {"value": world * samples_per_step * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "ms_sample": ms_sample, "ms_frame": ms_frame,
-                "parity_checked": parity_checked, "streams_per_workgroup": spw_used, "samples_per_step": samples_per_step, "blob": blob, "nb_a": int(api.check_model(blob)[1][1])}
+                "parity_checked": parity_checked, "streams_per_workgroup": spw_used, "samples_per_step": samples_per_step, "blob": blob, "nb_a": int(api.check_model(blob)[1][1]),
+                "envelope": envelope}
 
     n, F = a.streams, a.frames
     head = run_workload(n, F, a.int8, a.steps, a.warmup, fast=a.fast, fp16_fc=a.fp16_fc, spw=a.spw, densities=a.densities, check_streams=a.check_streams, skew=a.skew)
@@ -551,6 +595,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 weights/activations x f32 accumulate (GRU-A/GRU-B), f32 elsewhere" if a.int8 else "f32", "data": "synthetic",
             "parity_checked": parity_checked,
+            **({"envelope_checked": head["envelope"]["envelope_checked"], "envelope": head["envelope"]} if head.get("envelope") else {}),
             "config": {"workload": f"{n} concurrent streams (each with its own feature file) per GPU x {F} frames ({F * 160} samples) per step, "
                                    + ("int8 GRU weights (v_dot4_i32_i8)" if a.int8 else "fp32 weights")
                                    + ", register-resident block-sparse GRU-A, "
