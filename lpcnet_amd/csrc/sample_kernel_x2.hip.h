@@ -205,13 +205,17 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
     auto lds_addr = [](const void *ptr) __attribute__((always_inline)) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(unsigned char *)ptr; };
 
     const int T = n_frames * frame_len;                      // samples per stream in this launch
-#if LPCN_ENABLE_PROF      // per-phase shader-clock accounting of workgroup 0 (profiling builds only), clk summed over the half-steps of the launch:
+#if LPCN_ENABLE_PROF
+#ifndef LPCN_PROF_MASK
+#define LPCN_PROF_MASK 0xFFF          // which of the 12 slots are compiled in (a run with only the two barrier waits, 0x480, perturbs the kernel least)
+#endif
+    // per-phase shader-clock accounting of workgroup 0 (profiling builds only), clk summed over the half-steps of the launch:
     // 0 leader / thresholds / frame boundary, 1 GRU-B mat-vec, 2 GRU-B gates, 3 candidate heads, 4 P1 start values (wait for the indices, gather, cond),
     // 5 P1 items, 6 P1 close, 7 wait at barrier 1, 8 dual-FC prefetch + GRU-A gate stage, 9 tree, 10 wait at barrier 2
     unsigned long long *const prof = Ap->prof;
     unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     const bool profiling = prof != nullptr && blockIdx.x == 0;
-#define LPCN_X2_PROF(slot) do { if (profiling) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[slot] += now_ - tprev; tprev = now_; } } while (0)
+#define LPCN_X2_PROF(slot) do { if (((LPCN_PROF_MASK >> (slot)) & 1) && profiling) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[slot] += now_ - tprev; tprev = now_; } } while (0)
     if (profiling) tprev = __builtin_amdgcn_s_memtime();
 #else
 #define LPCN_X2_PROF(slot) do { } while (0)
@@ -587,6 +591,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                 }
                 LPCN_X2_PROF(2);
             }
+            // (Round 6 also gave these waves a share of P's start-value pass -- a round of update / reset rows and one of candidate inputs, or the candidate
+            // inputs alone, issued above the gates: 144.0 / 145.7 vs 147.0 M.  With only the barrier waits instrumented the chain waves have 1.3-2.2 k clk
+            // of slack per half-step, not the 4 k the full phase table shows; EXPERIMENTS.md.)
         } else {
             if (do_heads) {
                 hA_cur = gq + L::g_hA;
@@ -609,13 +616,15 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             // all three rounds are issued at once (48 loads per lane in flight), the update / reset rows are reduced and announced first -- the row owners
             // wait for those --, the candidate inputs, which only the gate stage behind the barrier needs, after the rest of the heads
             if (p0_wave) {
-            p0_open();
-            issue(0, 0); issue(1, 1); issue(2, 2);
-            reduce(0, 0); reduce(1, 1); reduce(2, 2);
-            p0_arrive();
-            issue(3, 0);
-            if (fifth) issue(4, 1);
-        }
+                p0_open();
+                LPCN_X2_PROF(1);                             // (head waves: slot 1 = wait for the indices, slot 2 = issue of the rounds)
+                issue(0, 0); issue(1, 1); issue(2, 2);
+                LPCN_X2_PROF(2);
+                reduce(0, 0); reduce(1, 1); reduce(2, 2);
+                p0_arrive();
+                issue(3, 0);
+                if (fifth) issue(4, 1);
+            }
             LPCN_X2_PROF(4);
             if (do_heads) {
                 head_step(head_step, std::integral_constant<int, JM>{}, std::integral_constant<int, NW>{});
@@ -644,6 +653,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                     if (v != want) __builtin_amdgcn_s_sleep(1);
                 } while (v != want);
             }
+            LPCN_X2_PROF(11);                                // wait for the start-value pass of the four row waves
             // slot 0 becomes the running row: candidate rows start from bias + diag*h -- or from the sums their head has parked --, update / reset
             // rows from their P0 cell; candidate rows further down park bias + diag*h in their own cell
 #pragma unroll

@@ -23,9 +23,9 @@ def main():
         steps = T * 160
         print(f"n={n} S={S} sample_kernel={ms:.2f} ms -> {n*steps/ms/1e3:.1f} M samples/s, us per sample step of a workgroup = {ms*1e3/steps:.2f}")
         if S == 8:
-            print("   per-wave clk per HALF-step [lead chain gatesB heads start items close B1wait P2 tree B2wait | sum]:")
+            print("   per-wave clk per HALF-step [lead chain|idxwait gatesB|p0issue heads start items close B1wait P2 tree B2wait p0wait | sum]:")
             for w in range(8):
-                r = prof[w*12:w*12+11] / (2 * steps)
+                r = prof[w*12:w*12+12] / (2 * steps)
                 print("   wave", w, " ".join("%6.0f" % x for x in r), "| %6.0f" % r.sum())
         else:
             print("   per-wave clk/step [B1wait P2 P3tail P4 P5 | gather close fcpre gruB items start P5a]:")
