@@ -200,7 +200,7 @@ extern "C" int lpcn_engine_create(lpcn_engine **out, int device, const lpcn_mode
     };
     if ((rc = upload_gru_a(m, a, nwv))) return fail(rc);
 #define UP(T, field, src, count) if ((rc = upload<T>(e, &a.field, src, count))) return fail(rc)
-    {                                                        // the tables in the blob's own [256][1152] order: the start-value pass of the two-group kernel and of the int8 PARITY kernels
+    if (!m->is_int8) {                                       // the tables in the blob's own [256][1152] order: the start-value pass of the two-group kernel
         UP(float, emb_nat_sig, m->emb_sig, (size_t)256 * LPCN_ROWS_A);
         UP(float, emb_nat_pred, m->emb_pred, (size_t)256 * LPCN_ROWS_A);
         UP(float, emb_nat_exc, m->emb_exc, (size_t)256 * LPCN_ROWS_A);

@@ -165,9 +165,7 @@ template <int S> struct Lds {
     static constexpr int PROD_BLOCKS = LPCN_PROD_BLOCKS, PROD_FIRST = 96 - PROD_BLOCKS;      // (the two assembly loops are generated for this split)
     static constexpr int prod_sz = S == 1 ? (PROD_BLOCKS + 7) * RB * 16 : 0;      // (S = 1, + 7 blocks: the chain wave's ring of eight reads ahead past the last block on its last trip)
     static constexpr int prod(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32; }
-    // int8 blobs: [384][S] partial sums of the candidate heads (PARITY: the rows' own cells are written by the start-value pass)
-    static constexpr int headc(int nb_b) { return hBh(nb_b, true) + S * 32; }
-    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? S * NA * 4 : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
+    static constexpr int total(int nb_b, bool i8) { return hBh(nb_b, i8) + S * 32 + (i8 ? 0 : prod_sz); }      // (bw pad: the GRU-B pipeline reads ahead)
     // int8 engine: the quantised states overlay the region of the fp32 engine's block-ordered float state
     static constexpr int xq     = hA;                               // [96 blocks][S] dwords: 4 int8 of one stream's block
     static constexpr int xqT    = hA + 384 * S;                     // [S][96] dwords: the same, stream-major (GRU-B input)
@@ -304,12 +302,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     using WT = typename std::conditional<I8, int, float4>::type;          // one resident item
     constexpr bool I8M = I8 && !FAST && S >= 2;             // PARITY, int8 blobs, S >= 2: an item's block products of all streams from one v_mfma_i32_4x4x4i8 (exact integers, like v_dot4)
     using HT = typename std::conditional<I8, typename std::conditional<I8M, int, typename XVec<S>::type>::type, float4>::type;   // one fetched state block
-    // PARITY, int8 blobs: the start values of ALL GRU-A rows as one element-wise pass over the tables in the blob's own row order (the form the two-group
-    // float kernel introduced, sample_kernel_x2.hip.h): lane i of the workgroup takes rows i, i + 512 (and i + 1024 on two waves) whoever owns them, the
-    // result goes to the rows' pre-activation cells / the candidate inputs, an arrival counter tells the owners.  The per-slot gather it replaces cost a
-    // wave ~125 vector instructions per sample in address arithmetic and per-slot bookkeeping -- a fifth of what an int8 workgroup issues, and two
-    // co-resident int8 workgroups are bound by instruction issue (VALU busy 0.89: profiles/r06_sq_counters_int8.csv).
-    constexpr bool P0 = I8 && !FAST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const sm_pre = (float *)(smem + L::pre);
     float *const sm_inh = (float *)(smem + L::inh);
@@ -334,7 +326,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const unsigned char *const sm_bblk = smem + L::bblk;
     const unsigned short *const sm_boff = (const unsigned short *)(smem + L::boff);
     const float *const sm_bw = (const float *)(smem + L::bw);
-    float *const sm_headc = (float *)(smem + L::headc(Ap->nb_b));      // (int8 blobs)
 
     const int tid0 = threadIdx.x;
     const int n_streams = Ap->n_streams, n_frames = Ap->n_frames, preload = Ap->preload, frame_len = Ap->frame_len;
@@ -347,7 +338,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     const auto *const emb_sig = as_global(Ap->emb_sig);
     const auto *const emb_pred = as_global(Ap->emb_pred);
     const auto *const emb_exc = as_global(Ap->emb_exc);
-    const auto *const emb_nat_sig = as_global(Ap->emb_nat_sig), *const emb_nat_pred = as_global(Ap->emb_nat_pred), *const emb_nat_exc = as_global(Ap->emb_nat_exc);
 
     // ------------------------------------------------------------------ resident weights ----
     // Float blobs denser than 32 items per lane: the first 28 items of a lane stay in VGPRs, the others are STREAMED -- re-fetched from
@@ -606,7 +596,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
     // Arrival counter in LDS for hand-offs without a workgroup barrier (FAST float GRU-B on the matrix pipe: every wave bumps it behind its LDS stores -- a wave's
     // LDS operations complete in order -- and only the gate waves wait for all eight)
     int gbseq = 0;                                           // samples handed off so far (identical in every wave)
-    int p0n = 0;                                             // start-value passes so far (int8 PARITY; identical in every wave)
     const uint32_t arrive_addr = flag_addr + 4;
     auto lds_arrive = [&]() {                                 // the same counter for hand-offs through LDS: no store round trip to wait for
         int one = 1;
@@ -991,112 +980,13 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                     LPCN_REMAT_V(r);
                     if (r >= 0) {
 #pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            if constexpr (P0) sm_headc[(r - 2 * NA) * S + s] = acc[s];
-                            else sm_pre[r * S + s] = acc[s];
-                        }
+                        for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc[s];
                     }
                 }
             };
             if (early_wave && !head_ready) { run_head(); head_ready = true; }     // first sample of the launch only
             const int jend = b3;
             const int jmode = __builtin_amdgcn_readfirstlane((allh0 && b1 >= JSTAR_MIN) ? 1 : 0);
-            // ---- P0 form of the start values (int8 PARITY)
-            float p0ld[P0 ? 3 : 1][P0 ? 3 * S : 1] = {};
-            auto p0_pass = [&]() __attribute__((always_inline)) {
-                if constexpr (P0) {
-                    ++p0n;
-                    if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) return;      // wave 0 leads the streams and is the last to get here: it takes no rows
-                    load_indices();
-                    const LPCN_GLOBAL char *tb[S][3];
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        tb[s][0] = (const LPCN_GLOBAL char *)emb_nat_sig + (size_t)((uint32_t)(gi[s] & 0xFF) * (uint32_t)(RA * 4));
-                        tb[s][1] = (const LPCN_GLOBAL char *)emb_nat_pred + (size_t)((uint32_t)((gi[s] >> 8) & 0xFF) * (uint32_t)(RA * 4));
-                        tb[s][2] = (const LPCN_GLOBAL char *)emb_nat_exc + (size_t)(((uint32_t)(gi[s] >> 16) & 0xFFu) * (uint32_t)(RA * 4));
-                        asm volatile("" : "+s"(tb[s][0]), "+s"(tb[s][1]), "+s"(tb[s][2]));      // (scalar row bases + one 32-bit lane offset per round)
-                    }
-                    uint32_t t_ = (uint32_t)tid0;
-                    LPCN_REMAT_V(t_);
-                    // the seven other waves: rounds of 448 rows -- waves 4..7 (g7 = 0..3) take three, waves 1..3 two; rows < 768 are update / reset rows
-                    const int wv_ = __builtin_amdgcn_readfirstlane((int)(t_ >> 6));
-                    const int g7 = wv_ >= 4 ? wv_ - 4 : wv_ + 3;
-                    const uint32_t i0 = ((uint32_t)g7 << 6) | (t_ & 63u);
-                    constexpr uint32_t RND = 64u * (LPCN_WAVES - 1);
-                    auto issue = [&](const int k) __attribute__((always_inline)) {
-                        const uint32_t rb = (i0 + RND * (uint32_t)k) * 4u;
-#pragma unroll
-                        for (int s = 0; s < S; ++s) {
-#pragma unroll
-                            for (int t = 0; t < 3; ++t) p0ld[k][3 * s + t] = *(const LPCN_GLOBAL float *)(tb[s][t] + rb);
-                        }
-                    };
-                    auto reduce = [&](const int k, const bool ur) __attribute__((always_inline)) {
-                        const int r = (int)i0 + (int)RND * k;
-                        float g[S];
-#pragma unroll
-                        for (int s = 0; s < S; ++s) g[s] = ((sm_cond[r * S + s] + p0ld[k][3 * s + 0]) + p0ld[k][3 * s + 1]) + p0ld[k][3 * s + 2];      // src/nnet.c:487-489
-                        if (ur) {                            // update / reset rows: (bias + diag*h) + input, as an accumulator (src/nnet.c:431-440, src/vec.h:306)
-                            const int n = r >= NA ? r - NA : r;
-                            const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
-#pragma unroll
-                            for (int s = 0; s < S; ++s) sm_pre[r * S + s] = acc_start<I8, FAST>((bias + diag * sm_hT[n * S + s]) + g[s]);
-                        } else {                             // candidate rows: the input part goes to the gate stage, the row starts from bias + diag*h
-                            const int n = r - 2 * NA;
-                            const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
-#pragma unroll
-                            for (int s = 0; s < S; ++s) {
-                                sm_inh[n * S + s] = g[s];
-                                sm_pre[r * S + s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
-                            }
-                        }
-                    };
-                    static_assert(2 * RND + 256 == RA && RND + 320 == 2 * NA, "rounds of the start-value pass");
-                    const bool third = g7 < 4;
-                    issue(0); issue(1);
-                    if (third) issue(2);
-                    reduce(0, true);
-                    if (g7 < 5) reduce(1, true); else reduce(1, false);
-                    if (third) reduce(2, false);
-                    lds_arrive();
-                }
-            };
-            auto p0_wait = [&]() __attribute__((always_inline)) {
-                int v;
-                const int want = p0n * (LPCN_WAVES - 1);
-                do {
-                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(arrive_addr) : "memory");
-                    v = __builtin_amdgcn_readfirstlane(v);
-                    if (v != want) __builtin_amdgcn_s_sleep(1);
-                } while (v != want);
-            };
-            // slot 0 becomes the running row: from the partial sums its head has parked, or from the cell the pass has filled
-            auto p0_start0 = [&]() __attribute__((always_inline)) {
-                int r = LPCN_ROW(0);
-                LPCN_REMAT_V(r);
-                r = r < 0 ? 0 : r;
-                const float *c = early_wave ? sm_headc + (r - 2 * NA) * S : sm_pre + r * S;
-#pragma unroll
-                for (int s = 0; s < S; ++s) acc[s] = c[s];
-            };
-            if constexpr (P0) {
-                if (jmode == 0) {
-                    wait_indices();
-                    p0_pass();
-                    p0_wait();
-                    p0_start0();
-                } else if (early_wave) {
-                    p0_start0();
-                } else {                                     // (a candidate slot without a head runs ahead from bias + diag*h formed here)
-                    int r = LPCN_ROW(0);
-                    LPCN_REMAT_V(r);
-                    r = r < 0 ? 0 : r;
-                    const int n = r - 2 * NA;
-                    const float bias = sm_abias[2 * r], diag = sm_abias[2 * r + 1];
-#pragma unroll
-                    for (int s = 0; s < S; ++s) acc[s] = acc_start<I8, FAST>(bias + diag * sm_hT[n * S + s]);
-                }
-            } else
             if (jmode == 0) {
                 row_pre(0, 0); row_pre(1, 1); row_pre(2, 2);
                 wait_indices();
@@ -1134,11 +1024,8 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             auto item = [&](const int j) -> bool {           // false: this wave has no more items
                 if ((j == 10 || j == 14 || j == 18) && j >= JSTAR_MIN && j <= JSTAR_MAX && __builtin_expect(j == jstar, 0)) {
                     if (jmode) {
-                        if constexpr (P0) p0_wait();         // the other slots' update / reset rows start from the cells of the pass
-                        else {
-                            row_init(1, 0, false);
-                            if (has2) { row_init(2, 1, false); gather(0, 0); }     // (two-slot waves already hold slot 0's rows in set 1)
-                        }
+                        row_init(1, 0, false);
+                        if (has2) { row_init(2, 1, false); gather(0, 0); }     // (two-slot waves already hold slot 0's rows in set 1)
                         __builtin_amdgcn_s_waitcnt(0xC07F);
                     }
                 }
@@ -1161,16 +1048,11 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
 #pragma unroll
             for (int j = 0; j < JG && j < NW; ++j) item(j);  // (no wave ends before JG: jmode needs b1 >= JSTAR_MIN > JG, others just fall through)
             if (jmode) {                                     // between two fully unrolled halves
-                if constexpr (P0) {
-                    wait_indices();
-                    p0_pass();
-                } else {
-                    row_pre(1, 1); row_pre(2, 2);
-                    wait_indices();
-                    load_indices();
-                    gather(1, 0);
-                    if (has2) gather(2, 1); else gather(0, 1);   // a third slot's rows are fetched when set 0 is free again (JSTAR)
-                }
+                row_pre(1, 1); row_pre(2, 2);
+                wait_indices();
+                load_indices();
+                gather(1, 0);
+                if (has2) gather(2, 1); else gather(0, 1);   // a third slot's rows are fetched when set 0 is free again (JSTAR)
             }
             // straight-line items JG..NW-1 with ONE exit branch (compile-time recursion instead of an unrolled
             // loop with a break, which the unroller refuses)
@@ -1195,7 +1077,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
             } else {
                 row_store(2);
             }
-            if (!P0 && jmode) {                              // input part of the candidate rows of slot 0 (the start-value pass has written it for int8 PARITY)
+            if (jmode) {                                     // input part of the candidate rows of slot 0
                 int r = LPCN_ROW(0);
                 LPCN_REMAT_V(r);
                 if (r >= 0) {
