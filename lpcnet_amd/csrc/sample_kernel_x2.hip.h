@@ -27,7 +27,7 @@
 namespace lpcn {
 
 #define LPCN_X2_LW 4            // the wave that leads the streams (tree walk, LPC predictor, mu-law): a head wave (model_pack.c gives it the shortest candidate slot) -- waves 0..3 start GRU-B's chains at once
-#define LPCN_X2_TW 5            // the wave that draws the KISS99 thresholds      (leader on wave 5 / 7: 139.3 / 138.2 M samples/s against 146.7 M on wave 4, round 6)
+#define LPCN_X2_TW 0            // the wave that draws the KISS99 thresholds: a chain wave -- they have the most slack at barrier 1 (wave 0 / 1 / 3 / 5 / 6: 149.5 / 148.9 / 145.0 / 147.4 / 143.5 M; leader on wave 5 / 7: 139.3 / 138.2 M against 146.7 M on wave 4, round 6)
 #define LPCN_X2_HG 10           // head items a row wave runs before it polls the leader's indices for the start-value pass (6 / 10 / 14 / 18: 145.0 / 146.7 / 146.2 / 144.3 M)
 
 struct LdsX2 {
@@ -762,11 +762,37 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             const int node_level = node > 0 ? 31 - __clz(node) : 0;
             const float *const thr_q = (const float *)(gq + L::g_thr);
             unsigned long long *const mask_q = (unsigned long long *)(gq + L::g_mask);
+            // the node's 16 products for all four streams from the matrix pipe, four columns at a time, like a GRU-A item: lane k of a quad holds stream k's
+            // state, v_mfma_f32_4x4x1 with C = -0.0 returns (stream k's value) x (this lane's weight) in register k, rounded once; the sums stay in the
+            // reference's order as packed adds over stream pairs (src/nnet.c:194-199) -- 16 MFMA + 32 packed adds instead of 64 multiplies + 64 adds
+            // (146.7 -> 148.3 M samples/s)
+            float sums[S];
+            {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                float hs[NB];
+                const float4 *hp = (const float4 *)(hB_q + (tid & 3) * NB);
+#pragma unroll
+                for (int qd = 0; qd < NB / 4; ++qd) { const float4 v4 = hp[qd]; hs[4 * qd] = v4.x; hs[4 * qd + 1] = v4.y; hs[4 * qd + 2] = v4.z; hs[4 * qd + 3] = v4.w; }
+                load_negz();
+                f2 s01 = {fcb, fcb}, s23 = {fcb, fcb};
+#pragma unroll
+                for (int jb = 0; jb < NB; jb += 4) {
+                    f4 pv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pv[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(hs[jb + c], fcw[jb + c], negz, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s01 = s01 + __builtin_shufflevector(pv[c], pv[c], 0, 1);
+                        s23 = s23 + __builtin_shufflevector(pv[c], pv[c], 2, 3);
+                    }
+                }
+                sums[0] = s01[0]; sums[1] = s01[1]; sums[2] = s23[0]; sums[3] = s23[1];
+            }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                float sum = fcb;
-#pragma unroll
-                for (int j = 0; j < NB; ++j) sum = sum + fcw[j] * hB_q[s * NB + j];                      // src/nnet.c:194-199
+                const float sum = sums[s];
                 const float v = fcf * lpcn_tanh(sum, sm_tansig);
                 const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
                 const float lg = v + vo;
