@@ -396,7 +396,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
         // ================================================================ interval A ===========
         // ---- shared pieces of the item chains (P1 of group P, candidate heads of group Q)
         float acc[S] = {};
-        constexpr int PF = 2;
+        constexpr int PF = 2;                                // (state blocks fetched 1 / 2 / 3 / 4 items ahead: 150.0 / 151.0 / 149.6 / 148.0 M)
         float4 hq[PF + 1] = {};
         const unsigned char *hA_cur = gp + L::g_hA;           // state blocks of the group whose items are running
         auto fetch_h = [&](const int j) __attribute__((always_inline)) {
