@@ -14,7 +14,7 @@ also     = (N = 1) the same step with BASELINE config 4's int8 GRU weights (`als
            generic int8 build) and config 2's 1024 streams, each oracle-checked like the headline.
 rt       = (N = 1) the half of the metric that is a DEADLINE: frame-at-a-time synthesis at the stream counts that bracket the 10-ms
            frame period (`rt.probe`), host wall time AND device time of every step; `realtime_streams_sustained` is the largest
-           measured count whose p99 step stays under 10 ms.
+           measured count whose p99.9 step stays under 10 ms.
 value    = whole-job 16 kHz samples per second (sum over GPUs / max-over-ranks time);
            concurrent real-time streams = value / 16000.
            Every stream of every rank has its own seeded feature file (1000 + rank*streams + s); after the timed loop
@@ -308,9 +308,10 @@ def rt_measure(a, counts, steps, warm, world, rank, local, dev, blob, int8):
             parity = len(pick)
         p50, p99, mx = float(np.percentile(timed, 50)), float(np.percentile(timed, 99)), float(timed.max())
         late = np.nonzero(timed >= FRAME_DEADLINE_MS)[0]
-        results.append({"streams": n, "steps": steps, "step_ms_p50": p50, "step_ms_p99": p99, "step_ms_p999": float(np.percentile(timed, 99.9)), "step_ms_max": mx,
+        p999 = float(np.percentile(timed, 99.9))
+        results.append({"streams": n, "steps": steps, "step_ms_p50": p50, "step_ms_p99": p99, "step_ms_p999": p999, "step_ms_max": mx,
                         "step_ms_mean": float(timed.mean()),
-                        "deadline_ms": FRAME_DEADLINE_MS, "meets_deadline_p99": bool(p99 < FRAME_DEADLINE_MS),
+                        "deadline_ms": FRAME_DEADLINE_MS, "meets_deadline_p99": bool(p99 < FRAME_DEADLINE_MS), "meets_deadline_p999": bool(p999 < FRAME_DEADLINE_MS),
                         "over_deadline_steps": int(late.size),
                         "device_ms_p50": float(np.percentile(tdev, 50)), "device_ms_p99": float(np.percentile(tdev, 99)), "device_ms_max": float(tdev.max()),
                         # every late step with both clocks: [step, wall ms, device ms] (at most 16 listed)
@@ -323,10 +324,11 @@ def rt_measure(a, counts, steps, warm, world, rank, local, dev, blob, int8):
         del d_feat, d_pcm
     if world > 1:
         for r in results:                                    # every rank must hold the deadline: the worst rank's figures
-            t = torch.tensor([r["step_ms_p50"], r["step_ms_p99"], r["step_ms_max"]], dtype=torch.float64, device="cpu" if a.share_device else dev)
+            t = torch.tensor([r["step_ms_p50"], r["step_ms_p99"], r["step_ms_max"], r["step_ms_p999"]], dtype=torch.float64, device="cpu" if a.share_device else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            r["step_ms_p50"], r["step_ms_p99"], r["step_ms_max"] = (float(x) for x in t.tolist())
+            r["step_ms_p50"], r["step_ms_p99"], r["step_ms_max"], r["step_ms_p999"] = (float(x) for x in t.tolist())
             r["meets_deadline_p99"] = bool(r["step_ms_p99"] < FRAME_DEADLINE_MS)
+            r["meets_deadline_p999"] = bool(r["step_ms_p999"] < FRAME_DEADLINE_MS)
         dist.barrier()
     return results
 
@@ -340,14 +342,14 @@ def rt_main(a, world, rank, local, dev):
     blob = synth.blob_bytes(synth.make_model(flavour="int8" if a.int8 else "float"))
     results = rt_measure(a, counts, steps, warm, world, rank, local, dev, blob, a.int8)
     if rank == 0:
-        ok = [r for r in results if r["meets_deadline_p99"]]
+        ok = [r for r in results if r["meets_deadline_p999"]]
         best = max(ok, key=lambda r: r["streams"]) if ok else None
         head = best or min(results, key=lambda r: r["streams"])
         from lpcnet_amd import api as _api
         out = {"metric": "16 kHz samples/sec & concurrent real-time streams, 1/2/4/8 MI355X",
                "value": world * head["streams"] * 160 / (head["step_ms_p50"] * 1e-3), "unit": "samples/s",
                "realtime_streams_sustained": world * best["streams"] if best else 0,
-               "realtime_streams_sustained_note": "largest measured stream count per GPU whose p99 step time (one 10-ms frame for every stream, enqueue + wait) "
+               "realtime_streams_sustained_note": "largest measured stream count per GPU whose p99.9 step time (one 10-ms frame for every stream, enqueue + wait; the worst step of a run shorter than 1000 steps) "
                                                   "stays under the 10-ms frame period, x GPUs; 0 = none of the measured counts does",
                "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": head["step_ms_mean"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -547,13 +549,13 @@ def main():
                                "streams_per_workgroup": r2["streams_per_workgroup"], "parity_checked": r2["parity_checked"],
                                "workload": f"BASELINE config 4's weights: {n} concurrent streams x {F} frames per step, int8 GRU-A / GRU-B (bit-exact against the reference's generic int8 build), fp32 dual FC"}
         probe = rt_measure(a, RT_PROBE_STREAMS, RT_PROBE_STEPS, 5, world, rank, local, dev, head["blob"], False)
-        ok = [r for r in probe if r["meets_deadline_p99"]]
+        ok = [r for r in probe if r["meets_deadline_p999"]]
         best = max(ok, key=lambda r: r["streams"]) if ok else None
         rt = {"sustained_streams": best["streams"] if best else 0,
               "note": "frame-at-a-time synthesis (one 10-ms frame for every stream per step, enqueue + wait, src/lpcnet_demo.c:203-219); `sustained_streams` = the "
-                      f"largest of the probed counts {RT_PROBE_STREAMS} whose p99 step over {RT_PROBE_STEPS} steps stays under the 10-ms frame period (0: none); "
+                      f"largest of the probed counts {RT_PROBE_STREAMS} whose p99.9 step over {RT_PROBE_STEPS} steps (in effect the slowest of them) stays under the 10-ms frame period (0: none); "
                       "`probe` carries host wall time and device time of the steps, every late step with both (tools: bench.py --rt --rt-sweep for other counts / longer runs)",
-              "p50": best["step_ms_p50"] if best else None, "p99": best["step_ms_p99"] if best else None, "max": best["step_ms_max"] if best else None,
+              "p50": best["step_ms_p50"] if best else None, "p99": best["step_ms_p99"] if best else None, "p999": best["step_ms_p999"] if best else None, "max": best["step_ms_max"] if best else None,
               "over_deadline_steps": best["over_deadline_steps"] if best else None, "device_ms_max": best["device_ms_max"] if best else None,
               "parity_checked": best["parity_checked"] if best else 0, "probe": probe}
 
