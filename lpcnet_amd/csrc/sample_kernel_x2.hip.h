@@ -485,6 +485,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
         static_assert(NP0 * 64 * 3 == 2 * NA && CW == S, "three rounds of the row waves' lanes cover GRU-A's update / reset rows");
         const bool p0_wave = p_active && wave >= P0W;
         uint32_t o_sig[S] = {}, o_pred[S] = {}, o_exc[S] = {}, o_cond[S] = {};      // byte offsets of the streams' table rows (scalar) -- the lane adds its row
+        constexpr int P0PERM = 0x3102;                       // waves 4, 5, 6, 7 take lanes 128.., 0.., 64.., 192.. of the pass: the half round on waves 5, 6 (on 6, 7 / 5, 7 / 4, 5: 149.5 / 149.8 / 147.5 vs 150.2 M)
         int i0 = 0;
         float ld[3][4 * S] = {};
         auto p0_open = [&]() __attribute__((always_inline)) {
@@ -505,9 +506,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             }
             int t_ = tid0;
             LPCN_REMAT_V(t_);
-            i0 = ((((t_ >> 6) + 2) & 3) << 6) | (t_ & 63);   // lane i0 of the 256 takes rows i0 + 256 k; the half round (k = 4: rows 1024..1151) goes to waves 6, 7
+            i0 = (((P0PERM >> (4 * ((t_ >> 6) & 3))) & 3) << 6) | (t_ & 63);   // lane i0 of the 256 takes rows i0 + 256 k; the half round (k = 4: rows 1024..1151) goes to the two waves with i0 < 128
         };
-        const bool fifth = wave >= 6;                        // (wave-uniform)
+        const bool fifth = ((P0PERM >> (4 * (wave & 3))) & 3) < 2;      // (wave-uniform)
         auto issue = [&](const int k, const int buf) __attribute__((always_inline)) {
             const uint32_t rb = (uint32_t)(i0 + 256 * k) * 4u;
 #pragma unroll
