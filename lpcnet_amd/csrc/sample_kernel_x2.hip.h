@@ -791,14 +791,22 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                 }
                 sums[0] = s01[0]; sums[1] = s01[1]; sums[2] = s23[0]; sums[3] = s23[1];
             }
+            // the four streams stage by stage -- four table lookups in flight, the masks stored at the end (a store per stream makes every stream a basic block
+            // of its own, and the compiler then runs them one behind the other)
+            float vq[S], thq[S];
+            unsigned long long mq[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) { vq[s] = lpcn_tanh(sums[s], sm_tansig); thq[s] = thr_q[s * 8 + node_level]; }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float sum = sums[s];
-                const float v = fcf * lpcn_tanh(sum, sm_tansig);
+                const float v = fcf * vq[s];
                 const float vo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
                 const float lg = v + vo;
-                const unsigned long long m = __ballot(thr_q[s * 8 + node_level] < lg) & (wave == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
-                if (lane == 0) mask_q[s * 8 + wave] = m;
+                mq[s] = __ballot(thq[s] < lg) & (wave == 0 ? 0x5555555555555554ull : 0x5555555555555555ull);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) mask_q[s * 8 + wave] = mq[s];
             }
             // wave LW: the prediction terms of Q's next sample that do not involve the sample about to be drawn (src/lpcnet.c:252,262)
             if (is_lw) {
