@@ -128,6 +128,9 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
     const bool has2 = (has_slot & 4) != 0;
     const int hl = __builtin_amdgcn_readfirstlane(as_global(Ap->a_head)[tid0 >> 6]);
     const bool early_wave = hl > 0;                          // wave-uniform: this wave computes the head of its candidate slot one sample ahead
+    // wave-uniform: no row of this wave starts from bias + diag*h formed in P1 -- slot 0 continues from its head's partial sums (or holds update / reset rows only), slots 1, 2
+    // hold no candidate rows: the slot start is then ONE cell read (the row waves of the benchmark model's dealing)
+    const bool plain_start = __builtin_amdgcn_readfirstlane(((early_wave || __ballot(row_reg[0] >= 2 * NA) == 0ull) && __ballot(row_reg[1] >= 2 * NA || row_reg[2] >= 2 * NA) == 0ull) ? 1 : 0) != 0;
 
     // ------------------------------------------------------------------ LDS residents -------
     {
@@ -657,6 +660,14 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             LPCN_X2_PROF(11);                                // wait for the start-value pass of the four row waves
             // slot 0 becomes the running row: candidate rows start from bias + diag*h -- or from the sums their head has parked --, update / reset
             // rows from their P0 cell; candidate rows further down park bias + diag*h in their own cell
+            if (plain_start) {
+                int r = LPCN_ROW(0);
+                LPCN_REMAT_V(r);
+                r = r < 0 ? 0 : r;
+                const float *c = pre_cell(r, gp);
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[s] = c[s];
+            } else {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 int r = LPCN_ROW(k);
@@ -674,6 +685,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
                     if (k == 0) acc[s] = (candidate && !parked) ? bv : c[s];
                     else if (candidate && live_row) c[s] = bv;
                 }
+            }
             }
             auto row_swap = [&](const int k_done, const int k_next) __attribute__((always_inline)) {   // finished row out, next row in
                 int r = LPCN_ROW(k_done), r2 = LPCN_ROW(k_next);
