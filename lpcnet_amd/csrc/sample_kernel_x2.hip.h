@@ -261,13 +261,6 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             }
         };
         auto publish_indices = [&]() __attribute__((always_inline)) { asm volatile("ds_write_b32 %0, %1" :: "v"(flag_p), "v"(seqP) : "memory"); };
-        auto wait_indices = [&]() __attribute__((always_inline)) {      // (the polls of this kernel do not sleep between reads: 156.1 vs 155.3 M with s_sleep 1)
-            int v;
-            do {
-                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_p) : "memory");
-                v = __builtin_amdgcn_readfirstlane(v);
-            } while (v != seqP);
-        };
         auto draw_thresholds = [&](const int ls) __attribute__((always_inline)) {           // src/nnet.c:178-184
             int *li = (int *)lead_p + ls * 8;
             uint32_t rng[4] = {(uint32_t)li[4], (uint32_t)li[5], (uint32_t)li[6], (uint32_t)li[7]};
@@ -492,10 +485,17 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
         float ld[3][4 * S] = {};
         auto p0_open = [&]() __attribute__((always_inline)) {
             int gi[S];
-            wait_indices();
-            {
+            {   // poll the flag and fetch the four index words in ONE LDS round trip (a wave's LDS operations complete in order: indices read behind a flag that has the
+                // new sequence number are the new ones): 156.9 -> 158.0 M.  The polls of this kernel do not sleep between reads (156.1 vs 155.3 M with s_sleep 1).  (The same merge for the chains' counter + the tree's state reads, and for P0's counter +
+                // slot 0's cell: 157.5 / 157.1 vs 157.7 M, not kept.)
                 typedef int i4 __attribute__((ext_vector_type(4)));
-                const i4 v = *(const i4 *)idx_p;
+                i4 v;
+                int f;
+                const uint32_t idx_a = lds_addr(idx_p);
+                do {
+                    asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f), "=&v"(v) : "v"(flag_p), "v"(idx_a) : "memory");
+                    f = __builtin_amdgcn_readfirstlane(f);
+                } while (f != seqP);
 #pragma unroll
                 for (int s = 0; s < S; ++s) gi[s] = __builtin_amdgcn_readfirstlane(v[s]);
             }
