@@ -28,7 +28,7 @@ timeout 300 python bench.py --streams 1 --no-cpu-baseline > $OUT/bench_single.js
 # the operating point the metric is named after: one frame per step for every stream against the 10-ms deadline, >= 500 steps
 # (round 6, VERDICT r5 item 3: 2000 consecutive steps at the sustained counts, wall AND device time of every step)
 timeout 900 python bench.py --rt --steps 2000 --rt-sweep 1024,6144,7168,8192 --no-cpu-baseline > $OUT/bench_rt_f32.json 2> $OUT/bench_rt_f32.err
-timeout 900 python bench.py --rt --steps 2000 --rt-sweep 1024,10240,10752 --no-cpu-baseline --int8 > $OUT/bench_rt_int8.json 2> $OUT/bench_rt_int8.err
+timeout 900 python bench.py --rt --steps 2000 --rt-sweep 1024,9216,9728,10240,10752 --no-cpu-baseline --int8 > $OUT/bench_rt_int8.json 2> $OUT/bench_rt_int8.err
 # trained-like (heavy-tailed) GRU-A sparsity: the 80-item variants, items past the 28th and their block indices streamed from L2
 timeout 300 python bench.py --skew 0.1 --no-cpu-baseline > $OUT/bench_skewed.json 2> $OUT/bench_skewed.err
 timeout 300 python bench.py --skew 0.1 --int8 --no-cpu-baseline > $OUT/bench_skewed_int8.json 2> $OUT/bench_skewed_int8.err
