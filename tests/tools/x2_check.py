@@ -11,7 +11,10 @@ from oracle import orc
 def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-    blob = synth.blob_bytes(synth.make_model())
+    kw = {}
+    if os.environ.get('X2_SKEW'): kw['skew'] = float(os.environ['X2_SKEW'])                # trained-like sparsity: the streamed-item variants
+    if os.environ.get('X2_DENS'): kw['densities'] = tuple(float(x) for x in os.environ['X2_DENS'].split(','))
+    blob = synth.blob_bytes(synth.make_model(**kw))
     om = orc.OracleModel(blob)
     bad = 0
     for n in (() if os.environ.get('X2_SKIP_PARITY') else (8, 16, 13, 5)):
