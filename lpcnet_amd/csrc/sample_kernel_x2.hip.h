@@ -849,14 +849,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, 2) void sample_kernel_x2(const Lpc
             for (int k = 0; k < NQ; ++k) a[k] = a[k] * rg[k] + sm_inh[tid + k * LPCN_WG_THREADS];
 #pragma unroll
             for (int k = 0; k < NQ; ++k) a[k] = lpcn_tanh(a[k], sm_tansig);
+            // item i = tid + 512 k is (neuron (tid >> 2) + 128 k, stream tid & 3): the stream is the lane's own for all three, and the block-ordered copy's address
+            // advances by a constant (32 blocks of 64 B + 8 pads of 16 B per 128 neurons)
+            const unsigned ut = (unsigned)tid;
+            const bool live_s = ((live_maskP >> (ut & 3u)) & 1) != 0;
+            unsigned char *const ha0 = gp + L::g_hA + L::ha_off((int)(ut >> 4)) + (ut & 3u) * 16u + ((ut >> 2) & 3u) * 4u;
+            static_assert(L::ha_off(32) == 32 * L::HA_STRIDE + 8 * 16 && LPCN_WG_THREADS == 512 && S == 4, "gate-stage address stride");
 #pragma unroll
             for (int k = 0; k < NQ; ++k) {
-                const int i = tid + k * LPCN_WG_THREADS;
-                const int n = i / S, s = i % S;
                 const float hnew = z[k] * hold[k] + (1.f - z[k]) * a[k];      // src/nnet.c:447
-                const float hv = ((live_maskP >> s) & 1) ? hnew : hold[k];
-                hT_p[i] = hv;
-                *(float *)(gp + L::g_hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv;
+                const float hv = live_s ? hnew : hold[k];
+                hT_p[tid + k * LPCN_WG_THREADS] = hv;
+                *(float *)(ha0 + k * L::ha_off(32)) = hv;
             }
         }
         LPCN_X2_PROF(8);
