@@ -1139,12 +1139,18 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) a[q] = act_tanh<FAST>(a[q], sm_tansig);
+                // item i = tid + 512 q is (neuron tid / S + (512 / S) q, stream tid % S): the stream is the lane's own in every round, and the block-ordered copy's
+                // address advances by a constant per round (128 / S blocks and their pads)
+                const unsigned ut = (unsigned)tid;
+                const bool live_s = ((live_mask >> (ut % (unsigned)S)) & 1) != 0;
+                constexpr int HA_ADV = L::ha_off(LPCN_WG_THREADS / 4 / S);
+                unsigned char *const ha0 = smem + L::hA + L::ha_off((int)((ut / (unsigned)S) >> 2)) + (ut % (unsigned)S) * 16u + ((ut / (unsigned)S) & 3u) * 4u;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int i = tid + q * LPCN_WG_THREADS;
                     const int n = i / S, s = i % S;
                     const float hnew = z[q] * hold[q] + (1.f - z[q]) * a[q];      // src/nnet.c:447
-                    const float hv = ((live_mask >> s) & 1) ? hnew : hold[q];
+                    const float hv = live_s ? hnew : hold[q];
                     if (FULL || i < NI) {
                         sm_hT[i] = hv;
                         if constexpr (I8) {                  // next sample's activations, quantised once (src/vec.h:311)
@@ -1152,7 +1158,7 @@ __global__ __launch_bounds__(LPCN_WG_THREADS, PACK2 ? 4 : 2) void sample_kernel(
                             smem[L::xq + ((n >> 2) * S + s) * 4 + (n & 3)] = qv;
                             smem[L::xqT + (s * 96 + (n >> 2)) * 4 + (n & 3)] = qv;
                         } else {
-                            *(float *)(smem + L::hA + L::ha_off(n >> 2) + s * 16 + (n & 3) * 4) = hv;
+                            *(float *)(ha0 + q * HA_ADV) = hv;
                         }
                     }
                 }
