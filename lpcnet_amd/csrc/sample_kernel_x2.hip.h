@@ -10,8 +10,8 @@
 // P4 (tree); the workgroup runs HALF-STEPS of two intervals and two barriers:
 //
 //      interval A:  P3 of the one group (its GRU-B chains on waves 0..3, its candidate heads on the head waves)
-//                   followed, on every wave, by P1 of the OTHER group            | barrier
-//      interval B:  P2 of that other group, then P4 of the first one             | barrier, the groups swap roles
+//                   followed, on every wave, by P1 of the OTHER group, then P4 (the tree) of the first one   | barrier
+//      interval B:  P2 of that other group                                                                   | barrier, the groups swap roles
 //
 // so a wave is never short of work that does not depend on the chain it has just fed: the leader / gather latency of one group's
 // P1 is covered by the other group's chain and heads, and the waves that used to wait ~2 k clk for GRU-B run the other group's
